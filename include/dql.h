@@ -1,0 +1,215 @@
+/*
+ * dql.h — C ABI of libdql_hip.so: the MI355X (gfx950) vectorised UAV-landing environment +
+ * tabular Double-Q trainer hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: the path sits behind
+ * Python classes.  Each entry point below names the reference interface it replaces; the Python
+ * host package `dql_multirotor_landing_amd` binds these with ctypes and re-exposes the reference's
+ * class/method names (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 (DQL_OK) or a negative dql_status; dql_last_error() gives
+ * the thread-local message of the last failure.  All pointers are plain host pointers unless the
+ * name says "dev".  A dql_ctx owns its device memory and stream; it is not thread-safe; calls on
+ * one ctx are stream-ordered and asynchronous until a dql_get_* / dql_stats / dql_sync call.
+ * No torch types, no C++ types.
+ */
+#ifndef DQL_H
+#define DQL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQL_ABI_VERSION 1
+
+typedef enum dql_status {
+  DQL_OK = 0,
+  DQL_EINVAL = -1, /* bad argument / unsupported configuration (Python: ValueError) */
+  DQL_EHIP = -2,   /* HIP runtime error (Python: RuntimeError) */
+  DQL_ESTATE = -3, /* call order violation, e.g. step before reset (Python: ValueError) */
+  DQL_ENOMEM = -4
+} dql_status;
+
+/* CheckResult codes, declaration order of pkg/mdp.py:68-77 */
+enum {
+  DQL_TERMINAL_CONTACT = 0,
+  DQL_TERMINAL_SUCCESS = 1,
+  DQL_TERMINAL_FLYZONE_X = 2,
+  DQL_TERMINAL_FLYZONE_Y = 3,
+  DQL_TERMINAL_FLYZONE_Z = 4,
+  DQL_TERMINAL_MINIMUM_ALTITUDE = 5,
+  DQL_TERMINAL_TIMEOUT = 6,
+  DQL_NON_TERMINAL_SUCCESS = 7,
+  DQL_NON_TERMINAL = 8,
+  DQL_N_CHECK_CODES = 9
+};
+
+/* Quirk switches.  mode="reference" = all set; mode="paper" = 0. */
+enum {
+  DQL_Q_FAIL_TERM_EVERY_STEP = 1 << 0,  /* B7  pkg/mdp.py:528-536 */
+  DQL_Q_STICKY_CHECK = 1 << 1,          /* B8  pkg/mdp.py:363-425 */
+  DQL_Q_SHAPING_SURVIVES_RESET = 1 << 2,/* B9  pkg/mdp.py:196-197,469-474 */
+  DQL_Q_FROZEN_ACC_REFERENCE = 1 << 3,  /* B19 pkg/observation_utils.py:137-150: last_velocity never updated */
+  DQL_Q_BOOTSTRAP_ON_POS_CHANGE = 1 << 4,/* B3  pkg/double_q_learning.py:139-145 */
+  DQL_Q_UPDATE_TABLE_A_ONLY = 1 << 5,   /* B1/B2 pkg/double_q_learning.py:101-108,136-146 */
+  DQL_Q_REFERENCE = 0x3f
+};
+
+enum { DQL_F32 = 0, DQL_F64 = 1 };
+enum { DQL_TRAJ_RPM = 0, DQL_TRAJ_EIGHT = 1 };
+
+#define DQL_MAX_LEVELS 5
+#define DQL_N_ACTIONS 3
+#define DQL_N_ANGLES 7
+#define DQL_STATES_PER_LEVEL (3 * 3 * 3 * DQL_N_ANGLES)            /* 189 */
+#define DQL_CELLS_PER_LEVEL (DQL_STATES_PER_LEVEL * DQL_N_ACTIONS) /* 567 */
+#define DQL_N_STATES (DQL_MAX_LEVELS * DQL_STATES_PER_LEVEL)       /* 945 */
+#define DQL_N_CELLS (DQL_MAX_LEVELS * DQL_CELLS_PER_LEVEL)         /* 2835 = (5,3,3,3,7,3) C-order */
+#define DQL_TARGET_FRAC_BITS 26 /* fixed-point scale of the int64 TD-target accumulators */
+
+/* One POD configuration block; the Python dataclass `DqlConfig` mirrors it field for field with the
+ * reference's defaults (constants harvested in SURVEY.md appendix A, cited per field). */
+typedef struct dql_config {
+  /* ---- MDP: pkg/mdp.py:87-147, 214-255 ---- */
+  int32_t working_curriculum_step; /* 0..4 */
+  int32_t two_axis;                /* 0: TrainingMdp (x / pitch), 1: x+y (SimulationMdp layout) */
+  uint32_t quirks;                 /* DQL_Q_* */
+  int32_t dtype;                   /* DQL_F32 | DQL_F64: arithmetic of the fused simulator kernel */
+  double f_ag, t_max, p_max, v_max, a_max;
+  double theta_max, delta_theta, beta, sigma_a, minimum_altitude;
+  double w_p, w_v, w_theta, w_dur, w_fail, w_succ;
+  double lim_p[DQL_MAX_LEVELS], lim_v[DQL_MAX_LEVELS], lim_a[DQL_MAX_LEVELS]; /* pkg/mdp.py:45-53 */
+  double vz_setpoint, yaw_setpoint; /* pkg/mdp.py:212 (-0.1 training), :580 (-0.4 simulation) */
+  /* ---- agent / trainer: pkg/trainer.py:31-33 ---- */
+  double gamma, alpha_min, alpha_omega;
+  /* ---- simulator (replaces Gazebo + RotorS + 5 ROS nodes) ---- */
+  double dt;           /* worlds/basic.world:64-70  0.002 */
+  int32_t manager_div; /* physics ticks per manager tick: 100 Hz -> 5 (launch/environment.launch:55) */
+  int32_t trajectory;  /* DQL_TRAJ_* (pkg/moving_platform.py:87-127) */
+  double gravity;      /* 9.8 (worlds/basic.world:36) */
+  double mass;         /* 0.68 + 4*0.009 + 1e-5 (hummingbird.xacro:29,32) */
+  double inertia[3];   /* composite diagonal about the base origin */
+  double arm_length, rotor_z;   /* 0.17, 0.01 */
+  double k_f, k_m;              /* 8.54858e-06, 0.016 */
+  double rotor_alpha_up, rotor_alpha_down; /* exp(-dt/0.0125), exp(-dt/0.025) (common.h:147-183) */
+  double rotor_max;             /* 838 */
+  double c_drag, c_roll;        /* 8.06428e-05, 1e-06 */
+  double k_R[3], k_W[3];        /* pkg/attitude_controller.py:86-87 */
+  double pid_vz[6];             /* Kp Ki Kd lower upper windup: launch/drone.launch:35-40 */
+  double pid_yaw[6];            /* launch/drone.launch:49-54 */
+  double bw_c;                  /* Butterworth c = 1 (pkg/filters.py:93) */
+  double mp_r_x, mp_t_x;        /* platform amplitude and speed, omega = t_x / r_x (environment.launch:60-72) */
+  double mp_dt;                 /* 1 / frequency = 0.01 */
+  double mp_top_z, mp_half_x, mp_half_y; /* landing surface 0.455, half extents 0.5 (+ drone half width) */
+  double drone_bottom;          /* base box half height 0.06 */
+  double z_init, init_sigma;    /* pkg/trainer.py:41 (4.0), p_max/3 (landing_simulation_env.py:189) */
+  int32_t init_uniform;         /* 0: N(0,sigma) at level 0 else U (TrainingLandingEnv.reset); 1: always U (Simulation env) */
+  int32_t per_env_platform;     /* 1: r_x, t_x drawn per env from the ranges below (BASELINE config 5) */
+  double mp_r_lo, mp_r_hi, mp_t_lo, mp_t_hi;
+  double noise_pos_sd, noise_vel_sd, kalman_q; /* scripts/manager_node.py:83-98 */
+} dql_config;
+
+/* Aggregated counters since the last dql_stats_reset (device-side reductions). */
+typedef struct dql_stats {
+  int64_t agent_steps;   /* launches of the fused step kernel */
+  int64_t decisions;     /* env-steps: (env, step) pairs in which an action was taken (reset periods excluded) */
+  int64_t episodes;      /* finished episodes */
+  int64_t by_code[DQL_N_CHECK_CODES]; /* terminal histogram by CheckResult code */
+  double reward_sum;     /* sum of step rewards over all decisions */
+  int64_t physics_ticks; /* global physics tick index */
+} dql_stats;
+
+typedef struct dql_ctx dql_ctx;
+
+/* ---- library ---- */
+int dql_abi_version(void);
+const char* dql_last_error(void);
+int dql_device_count(int* count);
+/* fill cfg with the reference defaults; training flavour */
+int dql_config_default(dql_config* cfg);
+
+/* ---- context: replaces gym.make("Landing-Training-v0") + DoubleQLearningAgent() (pkg/trainer.py:176-183,46-48) ---- */
+int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed, int64_t env_id_offset, dql_ctx** out);
+int dql_destroy(dql_ctx* ctx);
+int dql_sync(dql_ctx* ctx);
+int dql_n_envs(dql_ctx* ctx, int64_t* n);
+int dql_state_bytes_per_env(dql_ctx* ctx, int64_t* bytes);
+
+/* alpha(count) table: alpha[c] for c < n, alpha_min beyond (pkg/trainer.py:88-110, computed by the host exactly
+ * as the reference does so that device and oracle share bit-identical values) */
+int dql_set_alpha_table(dql_ctx* ctx, const double* alpha, int32_t n);
+/* Trainer creates a new env per curriculum level (pkg/trainer.py:172-183): new limits, every env re-enters via reset */
+int dql_set_curriculum(dql_ctx* ctx, int32_t working_curriculum_step);
+
+/* ---- env: TrainingLandingEnv.reset / .step (pkg/landing_simulation_env.py:167-282) ---- */
+/* mark envs for reset (mask NULL = all); the reset (placement + one agent period + first discrete state)
+ * is executed by the next step/train call, as the reference's reset() runs one agent period of simulation */
+int dql_reset(dql_ctx* ctx, const uint8_t* mask_or_null);
+/* one agent step with caller-supplied actions (uint8 per env, 0/1/2; two_axis: 2 per env); no table update */
+int dql_step(dql_ctx* ctx, const uint8_t* actions);
+/* n fused agent steps: on-device eps-greedy guess + step + TD-target accumulation + table apply
+ * (pkg/trainer.py:191-212 loop body for all envs at once) */
+int dql_train_steps(dql_ctx* ctx, int32_t n_steps, double eps);
+/* n greedy steps without learning (scripts/simulation.py:49-56) */
+int dql_eval_steps(dql_ctx* ctx, int32_t n_steps);
+
+/* per-env results of the last step (host out buffers of n_envs elements) */
+int dql_get_states(dql_ctx* ctx, int32_t* idx_x, int32_t* idx_y_or_null); /* packed ((((k*3+p)*3+v)*3+a)*7+theta) */
+int dql_get_rewards(dql_ctx* ctx, double* rewards);
+int dql_get_dones(dql_ctx* ctx, uint8_t* dones, int8_t* codes_or_null);
+int dql_get_actions(dql_ctx* ctx, uint8_t* actions);
+/* raw continuous state, field-major [n_fields][n_envs] as doubles (see dql_field_names) */
+int dql_get_sim_state(dql_ctx* ctx, double* out, int32_t n_fields_capacity);
+int dql_set_sim_state(dql_ctx* ctx, const double* in, int32_t n_fields);
+int dql_get_sim_ints(dql_ctx* ctx, int32_t* out, int32_t n_fields_capacity);
+int dql_set_sim_ints(dql_ctx* ctx, const int32_t* in, int32_t n_fields);
+int dql_n_fields(int32_t* n_real, int32_t* n_int);
+const char* dql_field_name(int32_t i, int32_t is_int);
+/* last latched observation per env: [6][n] = rel_p_x, rel_p_y, rel_v_x, rel_v_y, rel_a_x, rel_a_y */
+int dql_get_obs(dql_ctx* ctx, double* out);
+
+/* ---- tables: DoubleQLearningAgent.Q_table_a/_b/state_action_counter (pkg/double_q_learning.py:35-40) ---- */
+int dql_get_tables(dql_ctx* ctx, double* qa, double* qb, double* count); /* 2835 doubles each, C order (5,3,3,3,7,3) */
+int dql_set_tables(dql_ctx* ctx, const double* qa, const double* qb, const double* count);
+int dql_transfer(dql_ctx* ctx, int32_t k, double ratio); /* transfer_learning (pkg/double_q_learning.py:77-89) */
+
+/* ---- multi-GPU exchange: int64 accumulators [2][2835] = {sum of targets (fixed point), visits} ---- */
+int dql_set_sync_period(dql_ctx* ctx, int32_t k_steps); /* 1 = apply every step (single-GPU semantics) */
+int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device buffer to all-reduce (sum) */
+int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
+int dql_apply_accum(dql_ctx* ctx); /* apply the (all-reduced) accumulators to the base tables, clear them */
+int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy, for tests */
+int dql_set_accum(dql_ctx* ctx, const int64_t* in);
+
+/* ---- stats / timing ---- */
+int dql_stats_get(dql_ctx* ctx, dql_stats* out);
+int dql_stats_reset(dql_ctx* ctx);
+int dql_timer_start(dql_ctx* ctx); /* hipEventRecord on the ctx stream */
+int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, returns elapsed */
+/* average device duration of the fused step kernel over the launches since timer_start (per-launch events) */
+int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
+int dql_use_graph(dql_ctx* ctx, int32_t enable);
+
+/* ---- stateless batch operators (host arrays in/out, computed on the device; drop-in class methods) ---- */
+/* TrainingMdp.discrete_state (pkg/mdp.py:257-333): 4 x double[n] -> packed idx int32[n]; -1 where the reference raises */
+int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const double* rel_v, const double* rel_a,
+                   const double* angle, int64_t n, int32_t* idx_out);
+/* TrainingMdp continuous_action + discrete_state + check + reward for n independent MDPs, one transition each
+ * (pkg/mdp.py:335-560).  mdp_state: double[8][n] in/out = pitch_sp, shaping_p, shaping_v, shaping_a, cumulative,
+ * step_count, curriculum_check, check_code; prev_idx int32[n] in (-1 = none), idx out */
+int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, const uint8_t* action, const double* obs /*[7][n]:
+                       rel_p_x rel_p_y rel_v_x rel_a_x pitch abs_p_z contact*/, double* mdp_state, const int32_t* prev_idx,
+                       int32_t* idx_out, double* reward_out, uint8_t* done_out);
+/* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
+int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
+/* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:
+ * sa int32[n] = cell index (idx*3+action), ns int32[n] = packed next state; tables updated in place */
+int dql_agent_update(int device, double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns,
+                     const double* alpha, double gamma, const double* reward, int64_t n, uint32_t quirks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQL_H */

@@ -1,0 +1,609 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference's OWN Python modules.
+
+Runs ONLY in the build container (needs /root/reference).  The reference modules are imported
+unmodified from /root/reference/src/dql_multirotor_landing/src with in-memory stand-ins for the
+ROS packages that are not installed (rospkg, rospy, tf, geometry_msgs, the catkin-generated
+dql_multirotor_landing.msg, gym, tensorboard).  No reference source is copied: the outputs are
+data only (inputs + the values the reference computed for them).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz / *.json
+
+Groups:
+  G1  discretise          pkg/mdp.py:257-333
+  G2  episode traces      pkg/mdp.py:335-569   (check / reward / continuous_action / reset)
+  G2s simulation mdp      pkg/mdp.py:572-886
+  G4  agent               pkg/double_q_learning.py:77-146 (+ np.random stream consumption)
+  G5  schedules           pkg/trainer.py:88-138
+  G7  npy bytes           pkg/double_q_learning.py:42-53
+  G8  filters / pid       pkg/filters.py, pkg/pid.py:62-104
+  G9  attitude            pkg/attitude_controller.py:94-156  (tf.transformations is third-party and
+                          absent: quaternion_matrix / rotation_matrix are stand-ins written here, so
+                          the rotation construction is NOT reference arithmetic; the allocation
+                          matrix, error law, inverse allocation and clamp+sqrt are)
+  G10 assets              assets/{Q_table_a,Q_table_b,state_action_count}.npy (data copy)
+  G11 platform            pkg/moving_platform.py:87-127
+"""
+from __future__ import annotations
+
+import hashlib
+import io
+import json
+import math
+import shutil
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REF = Path("/root/reference")
+PKG_SRC = REF / "src" / "dql_multirotor_landing" / "src"
+OUT = Path(__file__).resolve().parent
+
+
+# --------------------------------------------------------------------------------------
+# stand-ins (in memory only)
+# --------------------------------------------------------------------------------------
+def _mod(name: str, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Bag:
+    """Generic message stand-in: attribute bag with nested auto-creation."""
+
+    def __init__(self, *a, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        v = _Bag()
+        object.__setattr__(self, k, v)
+        return v
+
+
+class Action:
+    def __init__(self, roll=0.0, pitch=0.0, yaw=0.0, v_z=0.0):
+        self.roll, self.pitch, self.yaw, self.v_z = roll, pitch, yaw, v_z
+
+
+class Observation:
+    def __init__(self, **kw):
+        for f in ("rel_p_x", "rel_p_y", "rel_p_z", "rel_v_x", "rel_v_y", "rel_v_z",
+                  "rel_a_x", "rel_a_y", "rel_a_z"):
+            setattr(self, f, float(kw.get(f, 0.0)))
+        self.contact = bool(kw.get("contact", False))
+
+
+class _Vec3:
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = x, y, z
+
+
+class _Vector3Stamped:
+    def __init__(self):
+        self.vector = _Vec3()
+        self.header = _Bag()
+
+
+class _Pose:
+    def __init__(self):
+        self.position = _Vec3()
+        self.orientation = _Bag(x=0.0, y=0.0, z=0.0, w=1.0)
+
+
+# --- tf.transformations stand-ins (public algorithm of transformations.py, restated) -----
+def quaternion_matrix(q):
+    q = np.array(q, dtype=np.float64, copy=True)  # (x, y, z, w)
+    n = np.dot(q, q)
+    if n < np.finfo(float).eps * 4.0:
+        return np.identity(4)
+    q *= math.sqrt(2.0 / n)
+    q = np.outer(q, q)
+    return np.array([
+        [1.0 - q[1, 1] - q[2, 2], q[0, 1] - q[2, 3], q[0, 2] + q[1, 3], 0.0],
+        [q[0, 1] + q[2, 3], 1.0 - q[0, 0] - q[2, 2], q[1, 2] - q[0, 3], 0.0],
+        [q[0, 2] - q[1, 3], q[1, 2] + q[0, 3], 1.0 - q[0, 0] - q[1, 1], 0.0],
+        [0.0, 0.0, 0.0, 1.0]])
+
+
+def rotation_matrix(angle, direction):
+    s, c = math.sin(angle), math.cos(angle)
+    d = np.array(direction, dtype=np.float64)
+    d = d / np.linalg.norm(d)
+    R = np.diag([c, c, c])
+    R += np.outer(d, d) * (1.0 - c)
+    d = d * s
+    R += np.array([[0.0, -d[2], d[1]], [d[2], 0.0, -d[0]], [-d[1], d[0], 0.0]])
+    M = np.identity(4)
+    M[:3, :3] = R
+    return M
+
+
+def quaternion_from_euler(ai, aj, ak):
+    ai, aj, ak = ai / 2.0, aj / 2.0, ak / 2.0
+    ci, si, cj, sj, ck, sk = math.cos(ai), math.sin(ai), math.cos(aj), math.sin(aj), math.cos(ak), math.sin(ak)
+    return np.array([si * cj * ck - ci * sj * sk, ci * sj * ck + si * cj * sk,
+                     ci * cj * sk - si * sj * ck, ci * cj * ck + si * sj * sk])
+
+
+class _FakeClock:
+    t = 0.0
+
+
+class _Time:
+    def __init__(self, t):
+        self._t = t
+
+    def to_sec(self):
+        return self._t
+
+    def __sub__(self, o):
+        return _Time(self._t - o._t)
+
+
+_PARAMS: dict = {}
+
+
+def install_standins():
+    _mod("rospkg", RosPack=lambda: types.SimpleNamespace(get_path=lambda name: str(REF / "src" / "dql_multirotor_landing")))
+    sys.path.insert(0, str(PKG_SRC))
+    import dql_multirotor_landing  # noqa: F401  (real package __init__, needs rospkg)
+    _mod("dql_multirotor_landing.msg", Action=Action, Observation=Observation)
+    rospy = _mod(
+        "rospy",
+        get_param=lambda k, d=None: _PARAMS.get(k, d),
+        loginfo=lambda *a, **k: None, logerr=lambda *a, **k: None, logwarn=lambda *a, **k: None,
+        Time=types.SimpleNamespace(now=lambda: _Time(_FakeClock.t)),
+        Publisher=lambda *a, **k: types.SimpleNamespace(publish=lambda m: None),
+        Subscriber=lambda *a, **k: None,
+        Rate=lambda hz: types.SimpleNamespace(sleep=lambda: None),
+        is_shutdown=lambda: True,
+    )
+    _mod("geometry_msgs")
+    _mod("geometry_msgs.msg", Vector3Stamped=_Vector3Stamped, Pose=_Pose, Vector3=_Vec3)
+    _mod("std_msgs")
+    _mod("std_msgs.msg", Float64=lambda data=0.0: types.SimpleNamespace(data=data))
+    _mod("tf")
+    _mod("tf.transformations", quaternion_matrix=quaternion_matrix, rotation_matrix=rotation_matrix,
+         quaternion_from_euler=quaternion_from_euler)
+    _mod("tf2_ros", TransformBroadcaster=lambda: None)
+    # trainer.py imports
+    gym = _mod("gym", Env=type("Env", (), {}), make=lambda *a, **k: None)
+    _mod("gym.envs")
+    _mod("gym.envs.registration", register=lambda **k: None)
+    _mod("gazebo_msgs")
+    _mod("gazebo_msgs.msg", ModelState=_Bag, ContactsState=_Bag)
+    _mod("gazebo_msgs.srv", GetModelState=_Bag, SetModelState=_Bag)
+    _mod("std_srvs")
+    _mod("std_srvs.srv", Empty=_Bag)
+    sys.modules["std_msgs.msg"].Bool = _Bag
+    sys.modules["tf.transformations"].euler_from_quaternion = lambda quaternion: (0.0, 0.0, 0.0)
+    _mod("rosgraph")
+    tb = _mod("torch.utils.tensorboard.writer", SummaryWriter=_Bag)
+    return rospy, gym, tb
+
+
+# --------------------------------------------------------------------------------------
+CODES = None  # CheckResult -> small int, in declaration order
+
+
+def code_of(cr):
+    return CODES[cr]
+
+
+def g1_discretise(mdp_mod, rng):
+    """Random + edge-case observations -> 5-tuples for every working level."""
+    out = {}
+    for k in range(5):
+        m = mdp_mod.TrainingMdp(k, 22.92, 20, 4.5)
+        lim_p = [1.0, 0.64, 0.4096, 0.262144, 0.16777216][: k + 1]
+        lim_v = [1.0, 0.8, 0.64, 0.512, 0.4096][: k + 1]
+        edges_p, edges_v = [], []
+        for i, (lp, lv) in enumerate(zip(lim_p, lim_v)):
+            cp = (1 / 3) if i == k else lim_p[i + 1] / lim_p[i]
+            cv = (1 / 3) if i == k else lim_v[i + 1] / lim_v[i]
+            for s in (-1, 1):
+                for e in (0.0, 1e-12, -1e-12, 1e-7, -1e-7):
+                    edges_p += [s * (lp + e), s * (lp * cp + e)]
+                    edges_v += [s * (lv + e), s * (lv * cv + e)]
+        edges_a = []
+        for s in (-1, 1):
+            for e in (0.0, 1e-12, -1e-12):
+                edges_a += [s * (0.416 + e), s * (0.416 / 3 + e), s * (1.0 + e), s * 1.5]
+        th = np.deg2rad(21.37723)
+        ang = np.linspace(-th, th, 7)
+        edges_th = list(ang) + list((ang[:-1] + ang[1:]) / 2) + [-0.5, 0.5, 0.0, 1e-17]
+        n_rand = 1500
+        p = np.concatenate([rng.uniform(-1.2, 1.2, n_rand) * 4.5, rng.normal(0, 0.3, 500) * 4.5,
+                            np.array(edges_p) * 4.5, np.zeros(len(edges_v) + len(edges_a) + len(edges_th))])
+        n = len(p)
+        v = rng.uniform(-1.2, 1.2, n) * 3.39411
+        a = rng.uniform(-1.3, 1.3, n) * 1.28
+        t = rng.uniform(-0.45, 0.45, n)
+        o = n_rand + 500 + len(edges_p)
+        v[o:o + len(edges_v)] = np.array(edges_v) * 3.39411
+        a[o + len(edges_v):o + len(edges_v) + len(edges_a)] = np.array(edges_a) * 1.28
+        t[o + len(edges_v) + len(edges_a):] = np.array(edges_th)
+        # half of the random ones get tiny v/a so that deep curriculum levels are reached
+        half = n_rand // 2
+        v[:half] *= rng.uniform(0, 0.6, half)
+        p[:half] *= rng.uniform(0, 0.4, half)
+        states = np.zeros((n, 5), dtype=np.int32)
+        for i in range(n):
+            obs = mdp_mod.ContinuousObservation(Observation(rel_p_x=p[i], rel_v_x=v[i], rel_a_x=a[i]), pitch=t[i])
+            states[i] = m.discrete_state(obs)
+        out[f"in_{k}"] = np.stack([p, v, a, t], axis=1)
+        out[f"state_{k}"] = states
+    np.savez_compressed(OUT / "g1_discretise.npz", **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def _rand_walk_obs(rng, n, k, scale):
+    """A smooth drone-relative trajectory: sinusoid of amplitude `scale` [m] + noise, v = dp/dt, a = dv/dt + noise."""
+    dt = 1 / 22.92
+    period = rng.uniform(4.0, 12.0)
+    ph = rng.uniform(0, 2 * np.pi)
+    t = np.arange(n) * dt
+    w = 2 * np.pi / period
+    p = scale * np.sin(w * t + ph) + rng.normal(0, 0.01 * scale, n)
+    v = scale * w * np.cos(w * t + ph) + rng.normal(0, 0.02 * scale, n)
+    a = -scale * w * w * np.sin(w * t + ph) + rng.normal(0, 0.3 * scale + 0.02, n)
+    return p, v, a
+
+
+def g2_traces(mdp_mod, rng):
+    """Scripted multi-episode traces through ONE TrainingMdp instance per working level.
+
+    ops: 0 = reset+discrete_state(obs) (as env.reset does), 1 = continuous_action(a); discrete_state; check; reward
+    kinds: 0 wander (non-terminal, ends by script length or fly zone y), 1 goal sitter (terminal success after 23
+    consecutive in-goal steps), 2 fly zone x, 3 minimum altitude, 4 contact / fly zone z, 5 timeout at step 459 (B18),
+    6 enter goal - leave - re-enter (sticky NON_TERMINAL_SUCCESS, B8; curriculum_check restart)
+    """
+    traces = {}
+    lim_p = [1.0, 0.64, 0.4096, 0.262144, 0.16777216]
+    for k in range(5):
+        m = mdp_mod.TrainingMdp(k, 22.92, 20, 4.5)
+        rows = []
+        goal_p = lim_p[k] / 3 * 4.5  # goal half-width in metres at the working level
+        for ep in range(16):
+            n = int(rng.integers(40, 140))
+            kind = ep % 7 if ep < 14 else 0
+            if kind == 5:
+                n = 470
+            amp = rng.uniform(1.0, 3.5)
+            if kind in (1,):
+                amp = 0.3 * goal_p
+            if kind == 5:
+                amp = rng.uniform(2.0, 3.0)
+            p, v, a = _rand_walk_obs(rng, n + 1, k, amp)
+            if kind == 6:
+                # in goal for 10 steps, far out for 15, back in goal until terminal success
+                pg, vg, ag = _rand_walk_obs(rng, n + 1, k, 0.2 * goal_p)
+                mask = np.ones(n + 1, dtype=bool); mask[12:27] = False
+                p = np.where(mask, pg, p + np.sign(p + 1e-9) * 0.5); v = np.where(mask, vg, v); a = np.where(mask, ag, a)
+            z = np.full(n + 1, 3.0) - 0.1 * np.arange(n + 1) / 22.92
+            y = np.zeros(n + 1)
+            contact = np.zeros(n + 1, dtype=bool)
+            if kind == 2:
+                p[n // 2:] += np.sign(rng.normal()) * np.linspace(0, 8, n + 1 - n // 2)  # leaves fly zone x
+            if kind == 3:
+                z[n // 2:] -= np.linspace(0, 4, n + 1 - n // 2)  # minimum altitude
+            if kind == 4 and ep < 7:
+                contact[n // 2:] = True
+            if kind == 4 and ep >= 7:
+                z[n // 2:] += np.linspace(0, 4, n + 1 - n // 2)  # fly zone z (too high)
+            if kind == 0 and ep >= 7:
+                y[n // 2:] += np.linspace(0, 6, n + 1 - n // 2)  # fly zone y
+            pitch_meas = rng.normal(0, 0.15, n + 1)
+            m.reset()
+            obs = mdp_mod.ContinuousObservation(
+                Observation(rel_p_x=p[0], rel_p_y=y[0], rel_v_x=v[0], rel_a_x=a[0], contact=contact[0]),
+                pitch=pitch_meas[0], abs_p_z=z[0])
+            s = m.discrete_state(obs)
+            rows.append([0, 2, p[0], y[0], v[0], a[0], pitch_meas[0], z[0], float(contact[0]),
+                         *s, -1, 0.0, 0, m._current_continuous_action.pitch, 0.0, 0, 0])
+            for i in range(1, n + 1):
+                act = int(rng.integers(0, 3))
+                m.continuous_action(act)
+                obs = mdp_mod.ContinuousObservation(
+                    Observation(rel_p_x=p[i], rel_p_y=y[i], rel_v_x=v[i], rel_a_x=a[i], contact=contact[i]),
+                    pitch=pitch_meas[i], abs_p_z=z[i])
+                s = m.discrete_state(obs)
+                info = m.check()
+                r = m.reward()
+                done = "Termination condition" in info
+                rows.append([1, act, p[i], y[i], v[i], a[i], pitch_meas[i], z[i], float(contact[i]),
+                             *s, code_of(m._check_result), r, int(done), m._current_continuous_action.pitch,
+                             float(m._cumulative_reward), m._step_count, m._curriculum_check])
+                if done:
+                    break
+        traces[f"trace_{k}"] = np.array(rows, dtype=np.float64)
+    np.savez_compressed(OUT / "g2_traces.npz", **traces)
+    cols = ["op", "action", "rel_p_x", "rel_p_y", "rel_v_x", "rel_a_x", "pitch", "abs_p_z", "contact",
+            "s_k", "s_p", "s_v", "s_a", "s_theta", "check_code", "reward", "done", "pitch_sp",
+            "cumulative", "step_count", "curriculum_check"]
+    return {"columns": cols, **{k: v.shape for k, v in traces.items()}}
+
+
+def g2s_simulation(mdp_mod, rng):
+    """SimulationMdp: two-axis discretisation + check codes (no reward)."""
+    m = mdp_mod.SimulationMdp(4, 22.92, 20)
+    rows = []
+    for ep in range(8):
+        n = int(rng.integers(20, 80))
+        px, vx, ax = _rand_walk_obs(rng, n + 1, 4, 0.3)
+        py, vy, ay = _rand_walk_obs(rng, n + 1, 4, 0.3)
+        z = 4.0 - 0.4 * np.arange(n + 1) / 22.92
+        contact = np.zeros(n + 1, dtype=bool)
+        if ep % 4 == 1:
+            contact[n - 3:] = True
+        if ep % 4 == 2:
+            py[n // 2:] += np.linspace(0, 7, n + 1 - n // 2)
+        if ep % 4 == 3:
+            z[n // 2:] -= np.linspace(0, 4, n + 1 - n // 2)
+        pitch = rng.normal(0, 0.15, n + 1); roll = rng.normal(0, 0.15, n + 1)
+        m.reset()
+        for i in range(n + 1):
+            if i > 0:
+                ax_, ay_ = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+                m.continuous_action(ax_, ay_)
+            else:
+                ax_, ay_ = 2, 2
+            obs = mdp_mod.ContinuousObservation(
+                Observation(rel_p_x=px[i], rel_p_y=py[i], rel_v_x=vx[i], rel_v_y=vy[i], rel_a_x=ax[i], rel_a_y=ay[i],
+                            contact=contact[i]), pitch=pitch[i], roll=roll[i], abs_p_z=z[i])
+            sx, sy = m.discrete_state(obs)
+            if i > 0:
+                info = m.check()
+                done = "Termination condition" in info
+                code = code_of(m._check_result)
+            else:
+                done, code = False, -1
+            rows.append([int(i > 0), ax_, ay_, px[i], py[i], vx[i], vy[i], ax[i], ay[i], pitch[i], roll[i], z[i],
+                         float(contact[i]), *sx, *sy, code, int(done),
+                         m._current_continuous_action.pitch, m._current_continuous_action.roll])
+            if done:
+                break
+    arr = np.array(rows, dtype=np.float64)
+    np.savez_compressed(OUT / "g2s_simulation.npz", trace=arr)
+    return {"trace": arr.shape, "columns": ["op", "ax", "ay", "px", "py", "vx", "vy", "aax", "aay", "pitch", "roll", "z",
+                                            "contact", "sx0..4", "sy0..4", "code", "done", "pitch_sp", "roll_sp"]}
+
+
+def g4_agent(dq_mod, rng):
+    out = {}
+    # (a) scripted update sequence under np.random.seed(42): final tables + RNG position
+    np.random.seed(42)
+    ag = dq_mod.DoubleQLearningAgent(5)
+    n = 4000
+    sa = np.stack([rng.integers(0, 5, n), rng.integers(0, 3, n), rng.integers(0, 3, n), rng.integers(0, 3, n),
+                   rng.integers(0, 7, n), rng.integers(0, 3, n)], axis=1)
+    # concentrate on few cells so that counts grow and bootstrap terms are non-trivial
+    sa[:, 0] = rng.integers(0, 2, n); sa[:, 4] = rng.integers(2, 5, n)
+    ns = np.stack([sa[:, 0], rng.integers(0, 3, n), rng.integers(0, 3, n), rng.integers(0, 3, n),
+                   rng.integers(2, 5, n)], axis=1)
+    rew = rng.normal(-5, 8, n)
+    alphas = np.zeros(n)
+    q_after = np.zeros(n)
+    for i in range(n):
+        c = ag.state_action_counter[tuple(sa[i])]
+        alpha = 0.02949 if c == 0 else float(np.max([np.float_power(1 / c, 0.51), 0.02949]))
+        alphas[i] = alpha
+        ag.update(tuple(int(x) for x in sa[i]), tuple(int(x) for x in ns[i]), alpha, 0.99, float(rew[i]))
+        q_after[i] = ag.Q_table_a[tuple(sa[i])]
+    out.update(upd_sa=sa.astype(np.int32), upd_ns=ns.astype(np.int32), upd_reward=rew, upd_alpha=alphas,
+               upd_q_after=q_after, upd_Qa=ag.Q_table_a.copy(), upd_Qb=ag.Q_table_b.copy(),
+               upd_count=ag.state_action_counter.copy(),
+               upd_rng_next_uniform=np.array([np.random.uniform(0, 1)]))
+    # (b) guess sequences: actions + RNG stream position (B4)
+    assets = dq_mod.DoubleQLearningAgent.load(REF / "assets")
+    states = np.stack([rng.integers(0, 5, 600), rng.integers(0, 3, 600), rng.integers(0, 3, 600),
+                       rng.integers(0, 3, 600), rng.integers(0, 7, 600)], axis=1)
+    for eps in (0.0, 0.5, 1.0):
+        np.random.seed(42)
+        acts = np.array([assets.guess(tuple(int(x) for x in s), eps) for s in states], dtype=np.int32)
+        out[f"guess_actions_eps{eps}"] = acts
+        out[f"guess_rng_next_eps{eps}"] = np.array([np.random.uniform(0, 1)])
+    out["guess_states"] = states.astype(np.int32)
+    # (c) predict over all 945 states of the reference's stage-4 tables
+    all_states = np.array([(k, p, v, a, t) for k in range(5) for p in range(3) for v in range(3)
+                           for a in range(3) for t in range(7)], dtype=np.int32)
+    out["predict_states"] = all_states
+    out["predict_actions"] = np.array([assets.predict(tuple(int(x) for x in s)) for s in all_states], dtype=np.int32)
+    # predict with ties (zeros) and on the scripted tables
+    out["predict_actions_scripted"] = np.array([ag.predict(tuple(int(x) for x in s)) for s in all_states], dtype=np.int32)
+    # (d) transfer learning incl. the k=0 wrap (B6)
+    t = dq_mod.DoubleQLearningAgent(5)
+    t.Q_table_a = rng.normal(0, 3, t.Q_table_a.shape); t.Q_table_b = rng.normal(0, 3, t.Q_table_b.shape)
+    out["tl_Qa_in"] = t.Q_table_a.copy(); out["tl_Qb_in"] = t.Q_table_b.copy()
+    ratios = [1.0, 0.8172650252856599, 0.8211253690681617, 0.8257273369742982, 0.8311571820651724]
+    for k in range(5):
+        t.transfer_learning(k, ratios[k])
+        out[f"tl_Qa_after{k}"] = t.Q_table_a.copy(); out[f"tl_Qb_after{k}"] = t.Q_table_b.copy()
+    np.savez_compressed(OUT / "g4_agent.npz", **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def g5_schedules(trainer_mod, dq_mod):
+    tr = trainer_mod.Trainer(save_path=Path("/tmp/unused"))
+    counts = np.arange(0, 3001)
+    alphas = np.zeros(len(counts))
+    for i, c in enumerate(counts):
+        tr._double_q_learning_agent.state_action_counter[0, 0, 0, 0, 0, 0] = c
+        alphas[i] = tr.alpha((0, 0, 0, 0, 0, 0))
+    eps0 = np.array([tr.exploration_rate(e, 0) for e in range(0, 2101)])
+    eps1 = np.array([tr.exploration_rate(e, 1) for e in range(0, 2101)])
+    ratios = np.array([tr.transfer_learning_ratio(k) for k in range(5)])
+    raised = False
+    try:
+        tr.transfer_learning_ratio(5)
+    except ValueError:
+        raised = True
+    np.savez_compressed(OUT / "g5_schedules.npz", counts=counts, alphas=alphas, eps_level0=eps0, eps_level1=eps1,
+                        ratios=ratios, ratio5_raises=np.array([raised]))
+    return {"alphas": alphas.shape, "ratio5_raises": raised}
+
+
+def g7_npy(dq_mod, tmp: Path):
+    tmp.mkdir(parents=True, exist_ok=True)
+    ag = dq_mod.DoubleQLearningAgent(5)
+    ag.Q_table_a[:] = np.arange(2835, dtype=np.float64).reshape(ag.Q_table_a.shape) * 0.25
+    ag.Q_table_b[:] = -ag.Q_table_a
+    ag.state_action_counter[:] = np.arange(2835).reshape(ag.Q_table_a.shape) % 7
+    ag.save(tmp)
+    res = {}
+    for name in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):
+        b = (tmp / name).read_bytes()
+        res[name] = {"sha256": hashlib.sha256(b).hexdigest(), "size": len(b), "header_hex": b[:128].hex()}
+    for name in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):
+        b = (REF / "assets" / name).read_bytes()
+        res["assets/" + name] = {"sha256": hashlib.sha256(b).hexdigest(), "size": len(b), "header_hex": b[:128].hex()}
+    (OUT / "g7_npy.json").write_text(json.dumps(res, indent=1))
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {k: v["size"] for k, v in res.items()}
+
+
+def g8_filters(filters_mod, pid_mod, rng):
+    out = {}
+    x = np.concatenate([np.ones(40), np.zeros(20), rng.normal(0, 1, 140)])
+    bw = filters_mod.ButterworthFilter()
+    out["bw_in"] = x
+    out["bw_out"] = np.array([bw.update(float(v)) for v in x])
+    for tag, sd in (("r0", 0.0), ("r01", 0.1)):
+        kf = filters_mod.KalmanFilter3D(process_variance=1e-4, measurement_variance=sd)
+        vel = np.cumsum(rng.normal(0, 0.05, (120, 3)), axis=0)
+        acc = np.zeros((119, 3))
+        for i in range(1, 120):
+            cur, last = _Vec3(*vel[i]), _Vec3(*vel[i - 1])
+            r = kf.filter(cur, 0.01 * i, last, 0.01 * (i - 1) if i % 17 else 0.01 * i)  # dt<=0 branch every 17th
+            acc[i - 1] = (r.vector.x, r.vector.y, r.vector.z)
+        out[f"kf_vel_{tag}"] = vel; out[f"kf_acc_{tag}"] = acc
+    # PID.output with a fake clock (pid.py:62-104).  __init__ would spin a ROS loop, so build via __new__
+    # and set exactly the attributes __init__ sets before load_params (pid.py:15-25).
+    from collections import deque
+    for tag, (kp, ki, kd, lo, hi, wind, sp) in {
+        "vz": (5.0, 10.0, 0.0, 0.0, 10.0, 10.0, -0.1),
+        "yaw": (8.0, 1.0, 0.0, -3.141592, 3.141592, 5.0, 0.0),
+        "kd": (2.0, 0.5, 0.3, -4.0, 4.0, 1.0, 0.2),
+    }.items():
+        pid = pid_mod.PID.__new__(pid_mod.PID)
+        pid.rate_hz = 1000.0
+        pid.error = deque([0.0, 0.0], maxlen=3)
+        pid.error_deriv = deque([0.0, 0.0, 0.0], maxlen=3)
+        pid.filter_error = filters_mod.ButterworthFilter()
+        pid.filter_deriv = filters_mod.ButterworthFilter()
+        pid.error_integral = 0.0
+        pid.current_state = 0.0
+        pid.setpoint = sp
+        pid.Kp, pid.Ki, pid.Kd = kp, ki, kd
+        pid.upper_limit, pid.lower_limit, pid.windup_limit = hi, lo, wind
+        pid.effort_pub = types.SimpleNamespace(publish=lambda m: None)
+        _FakeClock.t = 0.0
+        pid.prev_time = _Time(0.0)
+        n = 400
+        state = np.cumsum(rng.normal(0, 0.02, n)) + (0.7 if tag == "vz" else 0.0)
+        eff = np.zeros(n); integ = np.zeros(n)
+        for i in range(n):
+            _FakeClock.t = 0.002 * (i + 1)
+            if i % 5 == 0:
+                pid.current_state = float(state[i])  # manager publishes state at 100 Hz
+            pid.output()
+            eff[i] = float(pid.effort); integ[i] = float(pid.error_integral)
+        out[f"pid_{tag}_state"] = state; out[f"pid_{tag}_effort"] = eff; out[f"pid_{tag}_integral"] = integ
+        out[f"pid_{tag}_params"] = np.array([kp, ki, kd, lo, hi, wind, sp])
+    np.savez_compressed(OUT / "g8_filters.npz", **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def g9_attitude(att_mod, rng):
+    c = att_mod.AttitudeController()
+    out = {"A": c.allocation_matrix.copy(), "A_inv": np.linalg.inv(c.allocation_matrix)}
+    n = 200
+    quat = rng.normal(0, 1, (n, 4)); quat[:, :2] *= 0.2  # mostly small tilt, arbitrary yaw  (x, y, z, w)
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    omega = rng.normal(0, 0.5, (n, 3))
+    cmd = np.stack([rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-1, 1, n),
+                    rng.uniform(0, 10, n)], axis=1)  # roll, pitch, yaw_rate, thrust_z
+    cmd[:20, 0] = 0.0
+    cmd[20:30, 3] = 0.0  # forces the clamp at 0 (some rotor^2 < 0)
+    mom = np.zeros((n, 3)); rot = np.zeros((n, 4))
+    for i in range(n):
+        c.odometry = types.SimpleNamespace(orientation=quat[i], angular_velocity=omega[i])
+        c.state = att_mod.StateMsg(roll=cmd[i, 0], pitch=cmd[i, 1], yaw_rate=cmd[i, 2],
+                                   thrust=np.array([0.0, 0.0, cmd[i, 3]]))
+        mom[i] = c._compute_desired_moment()
+        rot[i] = c.compute_rotor_velocities()
+    out.update(quat_xyzw=quat, omega=omega, cmd=cmd, moment=mom, rotor=rot)
+    np.savez_compressed(OUT / "g9_attitude.npz", **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def g10_assets():
+    d = OUT / "assets"
+    d.mkdir(exist_ok=True)
+    for name in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):
+        arr = np.load(REF / "assets" / name, allow_pickle=False)
+        with open(d / name, "wb") as f:
+            np.save(f, arr)
+    return sorted(p.name for p in d.iterdir())
+
+
+def g11_platform(mp_mod):
+    out = {}
+    for tag, params in {
+        "rpm_launch": {"central_logic_node/moving_platform/trajectory_type": "rpm",
+                       "central_logic_node/moving_platform/t_x": "1.6", "central_logic_node/moving_platform/r_x": "2"},
+        "rpm_default": {},
+        "eight": {"central_logic_node/moving_platform/trajectory_type": "eight"},
+    }.items():
+        _PARAMS.clear(); _PARAMS.update(params)
+        mp = mp_mod.MovingPlatform()
+        n = 3000
+        arr = np.zeros((n, 5))
+        for i in range(n):
+            t = mp.t
+            pose, u, v = mp.update()
+            arr[i] = (t, pose.position.x, pose.position.y, u, v)
+        out[tag] = arr
+    _PARAMS.clear()
+    np.savez_compressed(OUT / "g11_platform.npz", **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def main():
+    global CODES
+    install_standins()
+    from dql_multirotor_landing import mdp as mdp_mod
+    from dql_multirotor_landing import double_q_learning as dq_mod
+    from dql_multirotor_landing import filters as filters_mod
+    from dql_multirotor_landing import pid as pid_mod
+    from dql_multirotor_landing import attitude_controller as att_mod
+    from dql_multirotor_landing import moving_platform as mp_mod
+    from dql_multirotor_landing import trainer as trainer_mod
+    CODES = {cr: i for i, cr in enumerate(mdp_mod.CheckResult)}
+    rng = np.random.default_rng(20250410)
+    summary = {
+        "check_codes": {cr.name: i for cr, i in CODES.items()},
+        "g1": g1_discretise(mdp_mod, rng),
+        "g2": g2_traces(mdp_mod, rng),
+        "g2s": g2s_simulation(mdp_mod, rng),
+        "g4": g4_agent(dq_mod, rng),
+        "g5": g5_schedules(trainer_mod, dq_mod),
+        "g7": g7_npy(dq_mod, Path("/tmp/dql_golden_npy")),
+        "g8": g8_filters(filters_mod, pid_mod, rng),
+        "g9": g9_attitude(att_mod, rng),
+        "g10": g10_assets(),
+        "g11": g11_platform(mp_mod),
+    }
+    (OUT / "summary.json").write_text(json.dumps(summary, indent=1, default=str))
+    print(json.dumps(summary, indent=1, default=str))
+
+
+if __name__ == "__main__":
+    main()
