@@ -1,0 +1,104 @@
+"""ctypes loader of csrc/libdql_hip.so (C ABI: include/dql.h).  There is no CPU fallback: if the library is
+missing, or no MI355X is visible when a device call is made, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from .config import DqlConfigC, N_CHECK_CODES
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libdql_hip.so"
+
+OK, EINVAL, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4
+
+
+class DqlStatsC(C.Structure):
+    _fields_ = [("agent_steps", C.c_int64), ("decisions", C.c_int64), ("episodes", C.c_int64),
+                ("by_code", C.c_int64 * N_CHECK_CODES), ("reward_sum", C.c_double), ("physics_ticks", C.c_int64)]
+
+
+# every symbol include/dql.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+_cfgp = C.POINTER(DqlConfigC)
+SYMBOLS = {
+    "dql_abi_version": (C.c_int, []),
+    "dql_last_error": (C.c_char_p, []),
+    "dql_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dql_config_default": (C.c_int, [_cfgp]),
+    "dql_create": (C.c_int, [_cfgp, C.c_int, _i64, _u64, _i64, C.POINTER(_vp)]),
+    "dql_destroy": (C.c_int, [_vp]),
+    "dql_sync": (C.c_int, [_vp]),
+    "dql_n_envs": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "dql_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "dql_set_alpha_table": (C.c_int, [_vp, _vp, _i32]),
+    "dql_set_curriculum": (C.c_int, [_vp, _i32]),
+    "dql_reset": (C.c_int, [_vp, _vp]),
+    "dql_step": (C.c_int, [_vp, _vp]),
+    "dql_train_steps": (C.c_int, [_vp, _i32, _dbl]),
+    "dql_eval_steps": (C.c_int, [_vp, _i32]),
+    "dql_get_states": (C.c_int, [_vp, _vp, _vp]),
+    "dql_get_rewards": (C.c_int, [_vp, _vp]),
+    "dql_get_dones": (C.c_int, [_vp, _vp, _vp]),
+    "dql_get_actions": (C.c_int, [_vp, _vp]),
+    "dql_get_sim_state": (C.c_int, [_vp, _vp, _i32]),
+    "dql_set_sim_state": (C.c_int, [_vp, _vp, _i32]),
+    "dql_get_sim_ints": (C.c_int, [_vp, _vp, _i32]),
+    "dql_set_sim_ints": (C.c_int, [_vp, _vp, _i32]),
+    "dql_n_fields": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32)]),
+    "dql_field_name": (C.c_char_p, [_i32, _i32]),
+    "dql_get_obs": (C.c_int, [_vp, _vp]),
+    "dql_get_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "dql_set_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "dql_transfer": (C.c_int, [_vp, _i32, _dbl]),
+    "dql_set_sync_period": (C.c_int, [_vp, _i32]),
+    "dql_set_windowed": (C.c_int, [_vp, _i32]),
+    "dql_accum_dev_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "dql_stream_handle": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dql_apply_accum": (C.c_int, [_vp]),
+    "dql_get_accum": (C.c_int, [_vp, _vp]),
+    "dql_set_accum": (C.c_int, [_vp, _vp]),
+    "dql_stats_get": (C.c_int, [_vp, C.POINTER(DqlStatsC)]),
+    "dql_stats_reset": (C.c_int, [_vp]),
+    "dql_timer_start": (C.c_int, [_vp]),
+    "dql_timer_stop": (C.c_int, [_vp, C.POINTER(_dbl)]),
+    "dql_kernel_timer": (C.c_int, [_vp, _i32]),
+    "dql_kernel_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    "dql_use_graph": (C.c_int, [_vp, _i32]),
+    "dql_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "dql_discretise": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
+    "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first (__graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dql_abi_version() != 1:
+            raise RuntimeError("libdql_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    """Map C status codes to the exception types the reference raises for the same conditions."""
+    if rc == OK:
+        return
+    msg = load().dql_last_error().decode(errors="replace")
+    if rc in (EINVAL, ESTATE):
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,907 @@
+// dql_hip.hip — kernels + C ABI (include/dql.h) of the MI355X UAV-landing / tabular Double-Q hot path.
+//
+// Kernels (all wave64, gfx950):
+//   k_step<T,BLOCK,LDS_TAB>  fused agent period: eps-greedy guess, 21/22 physics ticks (PID, SO(3) attitude law, rotor
+//                            model, rigid body, platform, 100 Hz observation pipeline), discretise/check/reward, TD target.
+//                            One lane per env, state in VGPRs, 16-byte coalesced quad loads/stores, per-workgroup LDS
+//                            accumulators (int64 fixed-point target sums + visit counts), wave64 shuffle reductions of the
+//                            counters, one global atomic per touched cell per workgroup.
+//   k_post                   folds the accumulators into the tables (mean-target contraction), advances the tick schedule.
+//   k_apply_window           multi-GPU: folds the all-reduced window accumulators into the base tables.
+//   small stateless kernels  drop-in single-call operators (discretise, mdp transition, predict, ordered update).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dql_device.hpp"
+
+using namespace dql;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                        \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) return fail(DQL_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+  } while (0)
+#define CHECK_CTX(ctx) do { if (!(ctx)) return fail(DQL_EINVAL, "null context"); } while (0)
+
+struct Sched { long long step_index, g0; int n_ticks, pad; };
+struct StatsDev { unsigned long long decisions, episodes, by_code[DQL_N_CHECK_CODES]; long long reward_fx; unsigned long long agent_steps; };
+
+// ---------------------------------------------------------------------------------------------
+// host -> device constants
+// ---------------------------------------------------------------------------------------------
+template <typename T> static DevC<T> make_devc(const dql_config& c) {
+  DevC<T> d;
+  memset(&d, 0, sizeof(d));
+  d.p_max = (T)c.p_max; d.v_max = (T)c.v_max; d.a_max = (T)c.a_max; d.theta_max = (T)c.theta_max; d.delta_theta = (T)c.delta_theta;
+  d.beta = (T)c.beta; d.sigma_a = (T)c.sigma_a; d.min_alt = (T)c.minimum_altitude;
+  d.w_p = (T)c.w_p; d.w_v = (T)c.w_v; d.w_theta = (T)c.w_theta; d.w_dur = (T)c.w_dur; d.w_fail = (T)c.w_fail; d.w_succ = (T)c.w_succ;
+  d.delta_t = (T)(1.0 / c.f_ag); d.f_ag = (T)c.f_ag; d.timeout_steps = (T)(c.t_max * c.f_ag);
+  for (int i = 0; i < 5; ++i) { d.lim_p[i] = (T)c.lim_p[i]; d.lim_v[i] = (T)c.lim_v[i]; d.lim_a[i] = (T)c.lim_a[i]; }
+  const double step = (c.theta_max - (-c.theta_max)) / 6.0;  // np.linspace(-theta_max, theta_max, 7), pkg/mdp.py:145
+  for (int i = 0; i < 6; ++i) d.angles[i] = (T)((double)i * step + (-c.theta_max));
+  d.angles[6] = (T)c.theta_max;
+  d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
+  for (int i = 0; i < 3; ++i) { d.I[i] = (T)c.inertia[i]; d.inv_I[i] = (T)(1.0 / c.inertia[i]); d.kR[i] = (T)c.k_R[i]; d.kW[i] = (T)c.k_W[i]; }
+  d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m;
+  d.aup = (T)c.rotor_alpha_up; d.adn = (T)c.rotor_alpha_down; d.omax = (T)c.rotor_max; d.cd = (T)c.c_drag; d.crd = (T)(c.c_roll / c.c_drag);
+  d.ia = (T)(1.0 / (4.0 * c.k_f)); d.ib = (T)(1.0 / (2.0 * c.arm_length * c.k_f)); d.ic = (T)(1.0 / (4.0 * c.k_f * c.k_m));
+  d.vz_kp = (T)c.pid_vz[0]; d.vz_ki = (T)c.pid_vz[1]; d.vz_lo = (T)c.pid_vz[3]; d.vz_hi = (T)c.pid_vz[4]; d.vz_wind = (T)c.pid_vz[5]; d.vz_sp = (T)c.vz_setpoint;
+  d.yw_kp = (T)c.pid_yaw[0]; d.yw_ki = (T)c.pid_yaw[1]; d.yw_lo = (T)c.pid_yaw[3]; d.yw_hi = (T)c.pid_yaw[4]; d.yw_wind = (T)c.pid_yaw[5]; d.yw_sp = (T)c.yaw_setpoint;
+  const double bc = c.bw_c, denom = 1 + bc * bc + 1.414 * bc;  // pkg/filters.py:94-106
+  d.bw_inv = (T)(1.0 / denom); d.bw_k1 = (T)(bc * bc - 1.414 * bc + 1); d.bw_k2 = (T)(-2 * bc * bc + 2);
+  d.mp_dt = (T)c.mp_dt; d.mp_top = (T)c.mp_top_z; d.mp_hx = (T)c.mp_half_x; d.mp_hy = (T)c.mp_half_y; d.bottom = (T)c.drone_bottom;
+  d.z_init = (T)c.z_init; d.init_sigma = (T)c.init_sigma;
+  d.noise_p = (T)c.noise_pos_sd; d.noise_v = (T)c.noise_vel_sd; d.kal_q = (T)c.kalman_q; d.kal_r = (T)(c.noise_vel_sd * c.noise_vel_sd);
+  d.mgr_dt = (T)(c.dt * c.manager_div);
+  d.mp_r = (T)c.mp_r_x; d.mp_w = (T)(c.mp_t_x / c.mp_r_x);
+  if (c.trajectory == DQL_TRAJ_EIGHT) { d.mp_r = (T)3.0; d.mp_w = (T)(0.8 / 3.0); }
+  d.gamma = c.gamma;
+  d.div = c.manager_div; d.traj = c.trajectory; d.init_uniform = c.init_uniform; d.working = c.working_curriculum_step;
+  d.per_env_platform = c.per_env_platform; d.two_axis = c.two_axis; d.quirks = c.quirks;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct InitArgs {
+  DevC<T> c; Quad<T>* sr; int4* si; long long n; unsigned long long seed; long long env_id_offset;
+  T hover, vz_integ, r_lo, r_hi, t_lo, t_hi;
+};
+template <typename T> __global__ void k_init(InitArgs<T> a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const DevC<T>& s = a.c;
+  uint32_t r[4];
+  philox4x32(0u, 0u, (uint32_t)(a.env_id_offset + i), STREAM_INIT, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+  Env<T> e;
+  memset(&e, 0, sizeof(e));
+  e.q[0] = T(1.0); e.p[2] = s.z_init;
+  for (int k = 0; k < 4; ++k) e.om[k] = a.hover;
+  e.vz_i = a.vz_integ;
+  e.kal_x_P = T(1.0); e.kal_y_P = T(1.0);
+  e.mp_r = s.mp_r; e.mp_w = s.mp_w;
+  if (s.per_env_platform && s.traj == DQL_TRAJ_RPM) {
+    e.mp_r = fma_(u24<T>(r[1]), a.r_hi - a.r_lo, a.r_lo);
+    const T tx = fma_(u24<T>(r[2]), a.t_hi - a.t_lo, a.t_lo);
+    e.mp_w = tx / e.mp_r;
+  }
+  e.mp_phase = T(6.28318530717958623200e+00) * u24<T>(r[0]);
+  platform_eval(s, e);
+  e.code = DQL_NON_TERMINAL; e.idx_x = -1; e.idx_y = -1; e.flags = FL_DONE; e.action = 2;
+  const long long n = a.n;
+  // every quad is written once here (also those the step kernel never touches in x-axis configs)
+  a.sr[11 * n + i] = Quad<T>{e.mp_v, e.vf_y, e.kal_y_x, e.kal_y_P};
+  a.sr[12 * n + i] = Quad<T>{T(0.0), T(0.0), T(0.0), T(0.0)};
+  a.sr[13 * n + i] = Quad<T>{e.mp_r, e.mp_w, T(0.0), T(0.0)};
+  store_env(e, a.sr, a.si, n, i, s);
+}
+
+template <typename T> struct StepArgs {
+  DevC<T> c;
+  Quad<T>* sr; int4* si;
+  const double* qa; const double* qb;
+  unsigned long long* accum;  // [2][DQL_N_CELLS]: target sums (fixed point), visits
+  StatsDev* stats;
+  const Sched* sched;
+  const uint8_t* actions;
+  long long n, env_id_offset;
+  unsigned long long seed;
+  double eps;
+  int mode;
+};
+
+DQL_DEV long long wave_sum(long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOCK) void k_step(StepArgs<T> a) {
+  __shared__ unsigned long long sT[DQL_N_CELLS];
+  __shared__ unsigned int sM[DQL_N_CELLS];
+  __shared__ unsigned long long sStat[4];
+  __shared__ double sQ[LDS_TAB ? 2 * DQL_N_CELLS : 1];
+  const int tid = threadIdx.x;
+  const int ncell = (a.c.working + 1) * DQL_CELLS_PER_LEVEL;
+  for (int c = tid; c < ncell; c += BLOCK) {
+    sT[c] = 0ull; sM[c] = 0u;
+    if (LDS_TAB) { sQ[c] = a.qa[c]; sQ[DQL_N_CELLS + c] = a.qb[c]; }
+  }
+  if (tid < 4) sStat[tid] = 0ull;
+  __syncthreads();
+  const long long step_index = a.sched->step_index, g0 = a.sched->g0;
+  const int n_ticks = a.sched->n_ticks;
+  const long long i = (long long)blockIdx.x * BLOCK + tid;
+  long long dec = 0, don = 0, rfx = 0;
+  if (i < a.n) {
+    Env<T> e;
+    load_env(e, a.sr, a.si, a.n, i, a.c);
+    const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
+    StepOut o;
+    if (LDS_TAB) o = agent_period(a.c, e, (const double*)sQ, (const double*)(sQ + DQL_N_CELLS), a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
+    else o = agent_period(a.c, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
+    store_env(e, a.sr, a.si, a.n, i, a.c);
+    if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
+    dec = o.decision; don = o.done; rfx = o.reward_fx;
+    if (o.done) atomicAdd(&a.stats->by_code[e.code], 1ull);
+  }
+  // wave64 shuffle reductions -> one LDS atomic per wave -> one global atomic per workgroup
+  dec = wave_sum(dec); don = wave_sum(don); rfx = wave_sum(rfx);
+  if ((tid & 63) == 0) {
+    if (dec) atomicAdd(&sStat[0], (unsigned long long)dec);
+    if (don) atomicAdd(&sStat[1], (unsigned long long)don);
+    if (rfx) atomicAdd(&sStat[2], (unsigned long long)rfx);
+  }
+  __syncthreads();
+  for (int c = tid; c < ncell; c += BLOCK) {
+    const unsigned int m = sM[c];
+    if (m) { atomicAdd(&a.accum[c], sT[c]); atomicAdd(&a.accum[DQL_N_CELLS + c], (unsigned long long)m); }
+  }
+  if (tid == 0) {
+    if (sStat[0]) atomicAdd(&a.stats->decisions, sStat[0]);
+    if (sStat[1]) atomicAdd(&a.stats->episodes, sStat[1]);
+    if (sStat[2]) atomicAdd((unsigned long long*)&a.stats->reward_fx, sStat[2]);
+  }
+}
+
+// mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)), count += m
+DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min) {
+  const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
+  const long long c0 = (long long)count[cell];
+  double shrink = 1.0;
+  long long j = 0;
+  for (; j < m && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
+  long long rem = m - j;
+  if (rem > 0) {
+    double base = 1.0 - alpha_min, pw = 1.0;
+    while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; }
+    shrink *= pw;
+  }
+  qa[cell] = tbar + (qa[cell] - tbar) * shrink;
+  count[cell] += (double)m;
+}
+
+struct PostArgs {
+  double* qa; double* count;         // work tables (the ones the step kernel reads)
+  long long* accum;                  // per-step accumulators, cleared here
+  long long* window;                 // multi-GPU window accumulators (windowed != 0)
+  const double* alpha_tab; int n_tab; double alpha_min;
+  Sched* sched; StatsDev* stats; double tick_ratio;  // 1 / (f_ag * dt)
+  int learn, windowed;
+};
+__global__ void k_post(PostArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < DQL_N_CELLS) {
+    const long long Tsum = a.accum[c], m = a.accum[DQL_N_CELLS + c];
+    if (m > 0) {
+      if (a.learn) {
+        if (a.windowed) { a.window[c] += Tsum; a.window[DQL_N_CELLS + c] += m; }
+        contract_cell(a.qa, a.count, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min);
+      }
+      a.accum[c] = 0; a.accum[DQL_N_CELLS + c] = 0;
+    }
+  }
+  if (c == 0) {
+    const long long j = a.sched->step_index + 1;
+    const long long t0 = (long long)floor((double)j * a.tick_ratio), t1 = (long long)floor((double)(j + 1) * a.tick_ratio);
+    a.sched->step_index = j; a.sched->g0 = t0; a.sched->n_ticks = (int)(t1 - t0);
+    a.stats->agent_steps += 1;
+  }
+}
+struct WindowArgs { double* qa_base; double* count_base; double* qa_work; double* count_work; long long* window; const double* alpha_tab; int n_tab; double alpha_min; };
+__global__ void k_apply_window(WindowArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= DQL_N_CELLS) return;
+  const long long Tsum = a.window[c], m = a.window[DQL_N_CELLS + c];
+  if (m > 0) {
+    contract_cell(a.qa_base, a.count_base, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min);
+    a.window[c] = 0; a.window[DQL_N_CELLS + c] = 0;
+  }
+  a.qa_work[c] = a.qa_base[c]; a.count_work[c] = a.count_base[c];
+}
+__global__ void k_mark_reset(int4* si, const uint8_t* mask, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mask && !mask[i]) return;
+  int4 v = si[i];
+  v.w |= (FL_DONE << 8);
+  si[i] = v;
+}
+__global__ void k_transfer(double* qa, double* qb, int k, int src, double ratio) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= DQL_CELLS_PER_LEVEL) return;
+  qa[k * DQL_CELLS_PER_LEVEL + i] = qa[src * DQL_CELLS_PER_LEVEL + i] * ratio;
+  qb[k * DQL_CELLS_PER_LEVEL + i] = qb[src * DQL_CELLS_PER_LEVEL + i] * ratio;
+}
+
+// ---- stateless operators ----
+template <typename T> __global__ void k_discretise(DevC<T> c, const double* p, const double* v, const double* acc, const double* ang, long long n, int* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = discretise(c, (T)p[i], (T)v[i], (T)acc[i], (T)ang[i]);
+}
+template <typename T>
+__global__ void k_mdp_transition(DevC<T> c, long long n, const uint8_t* action, const double* obs, double* ms, const int* prev_idx, int* idx_out,
+                                 double* reward_out, uint8_t* done_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T sp = (T)ms[0 * n + i], shp_p = (T)ms[1 * n + i], shp_v = (T)ms[2 * n + i], shp_a = (T)ms[3 * n + i], cum = (T)ms[4 * n + i];
+  int step_count = (int)ms[5 * n + i], cur_check = (int)ms[6 * n + i], code = (int)ms[7 * n + i];
+  sp = continuous_action(c, sp, (int)action[i]);
+  const T px = (T)obs[0 * n + i], py = (T)obs[1 * n + i], vx = (T)obs[2 * n + i], ax = (T)obs[3 * n + i], pitch = (T)obs[4 * n + i], z = (T)obs[5 * n + i];
+  const bool contact = obs[6 * n + i] != 0.0;
+  const int idx = discretise(c, px, vx, ax, pitch);
+  idx_out[i] = idx;
+  code = mdp_check(c, step_count, cur_check, code, prev_idx[i], idx < 0 ? 0 : idx, contact, px, py, z);
+  const T rew = mdp_reward(c, shp_p, shp_v, shp_a, cum, code, idx < 0 ? 0 : idx, px, vx, sp);
+  reward_out[i] = (double)rew; done_out[i] = code <= DQL_TERMINAL_TIMEOUT;
+  ms[0 * n + i] = sp; ms[1 * n + i] = shp_p; ms[2 * n + i] = shp_v; ms[3 * n + i] = shp_a; ms[4 * n + i] = cum;
+  ms[5 * n + i] = step_count; ms[6 * n + i] = cur_check; ms[7 * n + i] = code;
+}
+__global__ void k_predict(const double* qa, const double* qb, const int* idx, long long n, uint8_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
+}
+// ordered replay of DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146): inherently sequential -> one lane
+__global__ void k_update_seq(double* qa, double* qb, double* count, const int* sa, const int* ns, const double* alpha, double gamma,
+                             const double* reward, long long n, uint32_t quirks) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (long long i = 0; i < n; ++i) {
+    count[sa[i]] += 1;
+    const double q0 = qa[ns[i] * 3], q1 = qa[ns[i] * 3 + 1], q2 = qa[ns[i] * 3 + 2];
+    const int b = argmax3(q0, q1, q2);
+    const double best = b == 0 ? q0 : (b == 1 ? q1 : q2);
+    const int mask = idx_pos(sa[i] / 3) != idx_pos(ns[i]);
+    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qa[sa[i]]);
+    qa[sa[i]] += loss;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct dql_ctx {
+  dql_config cfg;
+  int device = 0;
+  long long n = 0;
+  unsigned long long seed = 0;
+  long long env_id_offset = 0;
+  int dtype = DQL_F32;
+  size_t real_size = 4;
+  void* sr = nullptr;  // Quad<T>[NQ_REAL][n]
+  int4* si = nullptr;
+  double *qa = nullptr, *qb = nullptr, *count = nullptr;          // work tables
+  double *qa_base = nullptr, *count_base = nullptr;               // multi-GPU base tables
+  long long *accum = nullptr, *window = nullptr;
+  double* alpha_tab = nullptr; int n_tab = 0;
+  Sched* sched = nullptr; StatsDev* stats = nullptr;
+  uint8_t* d_actions = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> kev;  // per-launch event pairs while the kernel timer is armed
+  bool kernel_timer = false;
+  long long timer_launches = 0;
+  int sync_period = 1;
+  bool windowed = false;
+  int lds_tables = 0;
+  int block = 0;  // 0 = auto
+  bool use_graph = false;
+};
+
+static int check_config(const dql_config* c) {
+  if (!c) return fail(DQL_EINVAL, "null config");
+  if (c->working_curriculum_step < 0 || c->working_curriculum_step >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "working_curriculum_step must be in 0..4");
+  if (c->dtype != DQL_F32 && c->dtype != DQL_F64) return fail(DQL_EINVAL, "dtype must be DQL_F32 or DQL_F64");
+  if (c->pid_vz[2] != 0.0 || c->pid_yaw[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported by the fused kernel (reference launch files use Kd = 0)");
+  if (c->manager_div < 1 || c->dt <= 0 || c->f_ag <= 0) return fail(DQL_EINVAL, "dt, f_ag, manager_div must be positive");
+  if (c->two_axis) return fail(DQL_EINVAL, "two_axis is not implemented in this build");
+  if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
+  return DQL_OK;
+}
+
+template <typename T> static int launch_init(dql_ctx* x) {
+  InitArgs<T> a;
+  a.c = make_devc<T>(x->cfg);
+  a.sr = (Quad<T>*)x->sr; a.si = x->si; a.n = x->n; a.seed = x->seed; a.env_id_offset = x->env_id_offset;
+  const dql_config& c = x->cfg;
+  a.hover = std::sqrt((T)(c.mass * c.gravity / (4.0 * c.k_f)));
+  a.vz_integ = (T)(c.mass * c.gravity / c.pid_vz[1]);
+  a.r_lo = (T)c.mp_r_lo; a.r_hi = (T)c.mp_r_hi; a.t_lo = (T)c.mp_t_lo; a.t_hi = (T)c.mp_t_hi;
+  const int B = 256;
+  hipLaunchKernelGGL(k_init<T>, dim3((unsigned)((x->n + B - 1) / B)), dim3(B), 0, x->stream, a);
+  HIP_TRY(hipGetLastError());
+  return DQL_OK;
+}
+
+static int host_sched_init(dql_ctx* x) {
+  const double ratio = 1.0 / (x->cfg.f_ag * x->cfg.dt);
+  Sched s;
+  s.step_index = 0; s.g0 = 0; s.n_ticks = (int)((long long)std::floor(1.0 * ratio) - 0); s.pad = 0;
+  HIP_TRY(hipMemcpyAsync(x->sched, &s, sizeof(s), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+
+template <typename T, int BLOCK, bool LDS_TAB> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+  StepArgs<T> a;
+  a.c = make_devc<T>(x->cfg);
+  a.sr = (Quad<T>*)x->sr; a.si = x->si; a.qa = x->qa; a.qb = x->qb; a.accum = (unsigned long long*)x->accum; a.stats = x->stats;
+  a.sched = x->sched; a.actions = x->d_actions; a.n = x->n; a.env_id_offset = x->env_id_offset; a.seed = x->seed; a.eps = eps; a.mode = mode;
+  hipLaunchKernelGGL((k_step<T, BLOCK, LDS_TAB>), dim3((unsigned)((x->n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, x->stream, a);
+}
+template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
+  int block = x->block;
+  if (block == 0) block = (x->n <= 32768) ? 64 : 256;  // small batches: one wave per workgroup spreads over more CUs
+  if (x->lds_tables) {
+    if (block == 64) launch_step_t<T, 64, true>(x, mode, eps); else if (block == 128) launch_step_t<T, 128, true>(x, mode, eps); else launch_step_t<T, 256, true>(x, mode, eps);
+  } else {
+    if (block == 64) launch_step_t<T, 64, false>(x, mode, eps); else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps); else launch_step_t<T, 256, false>(x, mode, eps);
+  }
+}
+static int launch_period(dql_ctx* x, int mode, double eps) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (x->kernel_timer) {
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, x->stream));
+  }
+  if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps); else launch_step_b<double>(x, mode, eps);
+  if (x->kernel_timer) { HIP_TRY(hipEventRecord(e1, x->stream)); x->kev.push_back(e0); x->kev.push_back(e1); }
+  PostArgs p;
+  p.qa = x->qa; p.count = x->count; p.accum = x->accum; p.window = x->window; p.alpha_tab = x->alpha_tab; p.n_tab = x->n_tab;
+  p.alpha_min = x->cfg.alpha_min; p.sched = x->sched; p.stats = x->stats; p.tick_ratio = 1.0 / (x->cfg.f_ag * x->cfg.dt);
+  p.learn = (mode == MODE_TRAIN); p.windowed = x->windowed ? 1 : 0;
+  hipLaunchKernelGGL(k_post, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, p);
+  x->timer_launches += 1;
+  HIP_TRY(hipGetLastError());
+  return DQL_OK;
+}
+
+// ---- typed host<->device copies (templates: C++ linkage) ----
+template <typename T> static int fetch_quads(dql_ctx* x, int q0, int nq, std::vector<T>& h) {
+  h.resize((size_t)nq * (size_t)x->n * 4);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(h.data(), (const char*)x->sr + (size_t)q0 * (size_t)x->n * 4 * sizeof(T), h.size() * sizeof(T), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+template <typename T> static int get_sim_state_t(dql_ctx* x, double* out) {
+  std::vector<T> h; int rc = fetch_quads<T>(x, 0, NQ_REAL, h); if (rc) return rc;
+  const long long n = x->n;
+  for (int f = 0; f < NF_REAL; ++f) { const int q = f / 4, k = f % 4; for (long long i = 0; i < n; ++i) out[(long long)f * n + i] = (double)h[((size_t)q * n + i) * 4 + k]; }
+  return DQL_OK;
+}
+template <typename T> static int set_sim_state_t(dql_ctx* x, const double* in) {
+  const long long n = x->n;
+  std::vector<T> h((size_t)NQ_REAL * n * 4);
+  for (int f = 0; f < NF_REAL; ++f) { const int q = f / 4, k = f % 4; for (long long i = 0; i < n; ++i) h[((size_t)q * n + i) * 4 + k] = (T)in[(long long)f * n + i]; }
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(x->sr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+template <typename T> static int get_rewards_t(dql_ctx* x, double* out) {
+  std::vector<T> h; int rc = fetch_quads<T>(x, 14, 1, h); if (rc) return rc;
+  for (long long i = 0; i < x->n; ++i) out[i] = (double)h[(size_t)i * 4];
+  return DQL_OK;
+}
+template <typename T> static int get_obs_t(dql_ctx* x, double* out) {
+  std::vector<T> h; int rc = fetch_quads<T>(x, 14, 2, h); if (rc) return rc;
+  const long long n = x->n;
+  for (long long i = 0; i < n; ++i) {
+    const T* a = &h[(size_t)i * 4]; const T* b = &h[((size_t)n + i) * 4];
+    out[0 * n + i] = a[1]; out[1 * n + i] = b[0]; out[2 * n + i] = a[2]; out[3 * n + i] = b[1]; out[4 * n + i] = a[3]; out[5 * n + i] = b[2];
+  }
+  return DQL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int dql_abi_version(void) { return DQL_ABI_VERSION; }
+const char* dql_last_error(void) { return g_err.c_str(); }
+int dql_device_count(int* count) {
+  if (!count) return fail(DQL_EINVAL, "null pointer");
+  HIP_TRY(hipGetDeviceCount(count));
+  return DQL_OK;
+}
+
+int dql_config_default(dql_config* c) {
+  if (!c) return fail(DQL_EINVAL, "null config");
+  memset(c, 0, sizeof(*c));
+  c->working_curriculum_step = 0; c->two_axis = 0; c->quirks = DQL_Q_REFERENCE; c->dtype = DQL_F32;
+  c->f_ag = 22.92; c->t_max = 20.0; c->p_max = 4.5; c->v_max = 3.39411; c->a_max = 1.28;
+  c->theta_max = 21.37723 * (M_PI / 180.0); c->delta_theta = 7.12574 * (M_PI / 180.0); c->beta = 1.0 / 3; c->sigma_a = 0.416; c->minimum_altitude = 0.2;
+  c->w_p = -100.0; c->w_v = -10.0; c->w_theta = -1.55; c->w_dur = -6.0; c->w_fail = -2.6; c->w_succ = 2.6;
+  const double lp[5] = {1.0, 0.64, 0.4096, 0.262144, 0.16777216}, lv[5] = {1.0, 0.8, 0.64, 0.512, 0.4096};
+  for (int i = 0; i < 5; ++i) { c->lim_p[i] = lp[i]; c->lim_v[i] = lv[i]; c->lim_a[i] = 1.0; }
+  c->vz_setpoint = -0.1; c->yaw_setpoint = 0.0;
+  c->gamma = 0.99; c->alpha_min = 0.02949; c->alpha_omega = 0.51;
+  c->dt = 0.002; c->manager_div = 5; c->trajectory = DQL_TRAJ_RPM; c->gravity = 9.8; c->mass = 0.68 + 4 * 0.009 + 1e-5;
+  {
+    const double m_r = 0.009, l = 0.17, h = 0.01, mb = m_r * 10.0;
+    const double ixx_r = 0.0833333 * mb * (0.015 * 0.015 + 0.003 * 0.003), iyy_r = 0.0833333 * mb * (0.1 * 0.1 + 0.003 * 0.003);
+    const double izz_r = 0.0833333 * mb * (0.1 * 0.1 + 0.015 * 0.015), inplane = 0.5 * (ixx_r + iyy_r);
+    c->inertia[0] = c->inertia[1] = 0.007 + 2 * m_r * (l * l + h * h) + 2 * m_r * h * h + 4 * inplane;
+    c->inertia[2] = 0.012 + 4 * m_r * l * l + 4 * izz_r;
+  }
+  c->arm_length = 0.17; c->rotor_z = 0.01; c->k_f = 8.54858e-06; c->k_m = 0.016;
+  c->rotor_alpha_up = std::exp(-0.002 / 0.0125); c->rotor_alpha_down = std::exp(-0.002 / 0.025); c->rotor_max = 838.0;
+  c->c_drag = 8.06428e-05; c->c_roll = 1e-06;
+  c->k_R[0] = 0.7; c->k_R[1] = 0.7; c->k_R[2] = 0.035; c->k_W[0] = 0.1; c->k_W[1] = 0.1; c->k_W[2] = 0.025;
+  const double pv[6] = {5.0, 10.0, 0.0, 0.0, 10.0, 10.0}, py[6] = {8.0, 1.0, 0.0, -3.141592, 3.141592, 5.0};
+  for (int i = 0; i < 6; ++i) { c->pid_vz[i] = pv[i]; c->pid_yaw[i] = py[i]; }
+  c->bw_c = 1.0; c->mp_r_x = 2.0; c->mp_t_x = 1.6; c->mp_dt = 0.01; c->mp_top_z = 0.455; c->mp_half_x = 0.55; c->mp_half_y = 0.55; c->drone_bottom = 0.06;
+  c->z_init = 4.0; c->init_sigma = 4.5 / 3; c->init_uniform = 0; c->per_env_platform = 0;
+  c->mp_r_lo = 1.0; c->mp_r_hi = 3.0; c->mp_t_lo = 0.8; c->mp_t_hi = 1.6;
+  c->noise_pos_sd = 0.0; c->noise_vel_sd = 0.0; c->kalman_q = 1e-4;
+  return DQL_OK;
+}
+
+int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed, int64_t env_id_offset, dql_ctx** out) {
+  if (!out) return fail(DQL_EINVAL, "null out pointer");
+  *out = nullptr;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (n_envs < 1 || n_envs > (1ll << 31)) return fail(DQL_EINVAL, "n_envs must be in 1..2^31");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(DQL_EHIP, "no HIP device visible: libdql_hip needs an MI355X (there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(DQL_EINVAL, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  dql_ctx* x = new dql_ctx();
+  x->cfg = *cfg; x->device = device; x->n = n_envs; x->seed = seed; x->env_id_offset = env_id_offset; x->dtype = cfg->dtype;
+  x->real_size = cfg->dtype == DQL_F32 ? 4 : 8;
+#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { dql_destroy(x); return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } } while (0)
+  HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&x->ev0)); HIP_TRY(hipEventCreate(&x->ev1));
+  ALLOC(x->sr, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size);
+  ALLOC(x->si, (size_t)x->n * sizeof(int4));
+  ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
+  ALLOC(x->qa_base, DQL_N_CELLS * sizeof(double)); ALLOC(x->count_base, DQL_N_CELLS * sizeof(double));
+  ALLOC(x->accum, 2 * DQL_N_CELLS * sizeof(long long)); ALLOC(x->window, 2 * DQL_N_CELLS * sizeof(long long));
+  ALLOC(x->sched, sizeof(Sched)); ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n);
+#undef ALLOC
+  HIP_TRY(hipMemsetAsync(x->sr, 0, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size, x->stream));
+  HIP_TRY(hipMemsetAsync(x->qa, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->qb, 0, DQL_N_CELLS * sizeof(double), x->stream));
+  HIP_TRY(hipMemsetAsync(x->count, 0, DQL_N_CELLS * sizeof(double), x->stream));
+  HIP_TRY(hipMemsetAsync(x->qa_base, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->count_base, 0, DQL_N_CELLS * sizeof(double), x->stream));
+  HIP_TRY(hipMemsetAsync(x->accum, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream)); HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream)); HIP_TRY(hipMemsetAsync(x->d_actions, 2, (size_t)x->n, x->stream));
+  rc = (x->dtype == DQL_F32) ? launch_init<float>(x) : launch_init<double>(x);
+  if (rc) { dql_destroy(x); return rc; }
+  rc = host_sched_init(x);
+  if (rc) { dql_destroy(x); return rc; }
+  // default alpha table (plateau only): callers install the reference schedule with dql_set_alpha_table
+  const double a0 = cfg->alpha_min;
+  rc = dql_set_alpha_table(x, &a0, 1);
+  if (rc) { dql_destroy(x); return rc; }
+  *out = x;
+  return DQL_OK;
+}
+
+int dql_destroy(dql_ctx* x) {
+  if (!x) return DQL_OK;
+  (void)hipSetDevice(x->device);
+  if (x->stream) (void)hipStreamSynchronize(x->stream);
+  for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window, x->alpha_tab, x->sched, x->stats, x->d_actions};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (x->ev0) (void)hipEventDestroy(x->ev0);
+  if (x->ev1) (void)hipEventDestroy(x->ev1);
+  if (x->stream) (void)hipStreamDestroy(x->stream);
+  delete x;
+  return DQL_OK;
+}
+
+int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipStreamSynchronize(x->stream)); return DQL_OK; }
+int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); *n = x->n; return DQL_OK; }
+int dql_state_bytes_per_env(dql_ctx* x, int64_t* bytes) {
+  CHECK_CTX(x);
+  // x-axis: quads 0-10 read + written, quads 14-15 written, int4 read + written
+  *bytes = (int64_t)((11 + 11 + 2) * 4 * x->real_size + 2 * sizeof(int4));
+  return DQL_OK;
+}
+
+int dql_set_alpha_table(dql_ctx* x, const double* alpha, int32_t n) {
+  CHECK_CTX(x);
+  if (!alpha || n < 1) return fail(DQL_EINVAL, "alpha table must have at least one entry");
+  if (alpha[n - 1] != x->cfg.alpha_min) return fail(DQL_EINVAL, "alpha table must end on the alpha_min plateau");
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (x->alpha_tab) HIP_TRY(hipFree(x->alpha_tab));
+  x->alpha_tab = nullptr;
+  HIP_TRY(hipMalloc((void**)&x->alpha_tab, (size_t)n * sizeof(double)));
+  HIP_TRY(hipMemcpy(x->alpha_tab, alpha, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  x->n_tab = n;
+  return DQL_OK;
+}
+
+int dql_set_curriculum(dql_ctx* x, int32_t k) {
+  CHECK_CTX(x);
+  if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
+  x->cfg.working_curriculum_step = k;
+  return dql_reset(x, nullptr);
+}
+
+int dql_reset(dql_ctx* x, const uint8_t* mask) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  uint8_t* dmask = nullptr;
+  if (mask) {
+    HIP_TRY(hipMalloc((void**)&dmask, (size_t)x->n));
+    HIP_TRY(hipMemcpyAsync(dmask, mask, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+  }
+  hipLaunchKernelGGL(k_mark_reset, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, x->stream, x->si, (const uint8_t*)dmask, (long long)x->n);
+  HIP_TRY(hipGetLastError());
+  if (dmask) { HIP_TRY(hipStreamSynchronize(x->stream)); HIP_TRY(hipFree(dmask)); }
+  return DQL_OK;
+}
+
+int dql_step(dql_ctx* x, const uint8_t* actions) {
+  CHECK_CTX(x);
+  if (!actions) return fail(DQL_EINVAL, "actions must not be null (use dql_train_steps / dql_eval_steps for on-device action selection)");
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(x->d_actions, actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));  // the caller's buffer may be reused right after return
+  return launch_period(x, MODE_EXTERNAL, 0.0);
+}
+int dql_train_steps(dql_ctx* x, int32_t n_steps, double eps) {
+  CHECK_CTX(x);
+  if (n_steps < 0) return fail(DQL_EINVAL, "n_steps must be >= 0");
+  HIP_TRY(hipSetDevice(x->device));
+  for (int i = 0; i < n_steps; ++i) { int rc = launch_period(x, MODE_TRAIN, eps); if (rc) return rc; }
+  return DQL_OK;
+}
+int dql_eval_steps(dql_ctx* x, int32_t n_steps) {
+  CHECK_CTX(x);
+  if (n_steps < 0) return fail(DQL_EINVAL, "n_steps must be >= 0");
+  HIP_TRY(hipSetDevice(x->device));
+  for (int i = 0; i < n_steps; ++i) { int rc = launch_period(x, MODE_EVAL, 0.0); if (rc) return rc; }
+  return DQL_OK;
+}
+
+// ---- getters ----
+static int fetch_ints(dql_ctx* x, std::vector<int4>& h) {
+  h.resize((size_t)x->n);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(h.data(), x->si, (size_t)x->n * sizeof(int4), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+int dql_get_states(dql_ctx* x, int32_t* idx_x, int32_t* idx_y) {
+  CHECK_CTX(x);
+  std::vector<int4> h; int rc = fetch_ints(x, h); if (rc) return rc;
+  for (long long i = 0; i < x->n; ++i) { if (idx_x) idx_x[i] = h[i].x; if (idx_y) idx_y[i] = h[i].y; }
+  return DQL_OK;
+}
+int dql_get_dones(dql_ctx* x, uint8_t* dones, int8_t* codes) {
+  CHECK_CTX(x);
+  std::vector<int4> h; int rc = fetch_ints(x, h); if (rc) return rc;
+  for (long long i = 0; i < x->n; ++i) { if (dones) dones[i] = ((h[i].w >> 8) & FL_DONE) ? 1 : 0; if (codes) codes[i] = (int8_t)(h[i].w & 0xff); }
+  return DQL_OK;
+}
+int dql_get_actions(dql_ctx* x, uint8_t* actions) {
+  CHECK_CTX(x);
+  std::vector<int4> h; int rc = fetch_ints(x, h); if (rc) return rc;
+  for (long long i = 0; i < x->n; ++i) actions[i] = (uint8_t)((h[i].w >> 16) & 0xff);
+  return DQL_OK;
+}
+int dql_get_sim_state(dql_ctx* x, double* out, int32_t cap) {
+  CHECK_CTX(x);
+  if (!out || cap < NF_REAL) return fail(DQL_EINVAL, "out buffer must hold 64 fields x n_envs doubles");
+  return x->dtype == DQL_F32 ? get_sim_state_t<float>(x, out) : get_sim_state_t<double>(x, out);
+}
+int dql_set_sim_state(dql_ctx* x, const double* in, int32_t nf) {
+  CHECK_CTX(x);
+  if (!in || nf != NF_REAL) return fail(DQL_EINVAL, "in buffer must hold exactly 64 fields x n_envs doubles");
+  return x->dtype == DQL_F32 ? set_sim_state_t<float>(x, in) : set_sim_state_t<double>(x, in);
+}
+int dql_get_sim_ints(dql_ctx* x, int32_t* out, int32_t cap) {
+  CHECK_CTX(x);
+  if (!out || cap < NF_INT) return fail(DQL_EINVAL, "out buffer must hold 7 fields x n_envs int32");
+  std::vector<int4> h; int rc = fetch_ints(x, h); if (rc) return rc;
+  const long long n = x->n;
+  for (long long i = 0; i < n; ++i) {
+    out[0 * n + i] = h[i].x; out[1 * n + i] = h[i].y; out[2 * n + i] = h[i].z & 0xffff; out[3 * n + i] = (h[i].z >> 16) & 0xffff;
+    out[4 * n + i] = h[i].w & 0xff; out[5 * n + i] = (h[i].w >> 8) & 0xff; out[6 * n + i] = (h[i].w >> 16) & 0xff;
+  }
+  return DQL_OK;
+}
+int dql_set_sim_ints(dql_ctx* x, const int32_t* in, int32_t nf) {
+  CHECK_CTX(x);
+  if (!in || nf != NF_INT) return fail(DQL_EINVAL, "in buffer must hold exactly 7 fields x n_envs int32");
+  const long long n = x->n;
+  std::vector<int4> h((size_t)n);
+  for (long long i = 0; i < n; ++i)
+    h[i] = make_int4(in[0 * n + i], in[1 * n + i], (in[2 * n + i] & 0xffff) | (in[3 * n + i] << 16),
+                     (in[4 * n + i] & 0xff) | ((in[5 * n + i] & 0xff) << 8) | ((in[6 * n + i] & 0xff) << 16));
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(x->si, h.data(), (size_t)n * sizeof(int4), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+static const char* const k_real_names[NF_REAL] = {
+    "px", "py", "pz", "vx", "vy", "vz", "qw", "qx", "qy", "qz", "wx", "wy", "wz", "om0", "om1", "om2",
+    "om3", "vz_i", "vz_x1", "vz_x2", "vz_y1", "vz_y2", "vz_y3", "vz_state",
+    "yw_i", "yw_x1", "yw_x2", "yw_y1", "yw_y2", "yw_y3", "yw_state", "pitch_sp",
+    "mp_phase", "mp_x", "mp_u", "vf_x", "kal_x_x", "kal_x_P", "shp_x_p", "shp_x_v",
+    "shp_x_a", "cum_x", "roll_sp", "mp_y", "mp_v", "vf_y", "kal_y_x", "kal_y_P",
+    "shp_y_p", "shp_y_v", "shp_y_a", "cum_y", "mp_r", "mp_w", "pad0", "pad1",
+    "reward", "obs_p_x", "obs_v_x", "obs_a_x", "obs_p_y", "obs_v_y", "obs_a_y", "pad2"};
+static const char* const k_int_names[NF_INT] = {"idx_x", "idx_y", "step_count", "cur_check", "code", "flags", "action"};
+int dql_n_fields(int32_t* n_real, int32_t* n_int) { if (n_real) *n_real = NF_REAL; if (n_int) *n_int = NF_INT; return DQL_OK; }
+const char* dql_field_name(int32_t i, int32_t is_int) {
+  if (is_int) return (i >= 0 && i < NF_INT) ? k_int_names[i] : nullptr;
+  return (i >= 0 && i < NF_REAL) ? k_real_names[i] : nullptr;
+}
+int dql_get_rewards(dql_ctx* x, double* rewards) {
+  CHECK_CTX(x);
+  if (!rewards) return fail(DQL_EINVAL, "null pointer");
+  return x->dtype == DQL_F32 ? get_rewards_t<float>(x, rewards) : get_rewards_t<double>(x, rewards);
+}
+int dql_get_obs(dql_ctx* x, double* out) {
+  CHECK_CTX(x);
+  if (!out) return fail(DQL_EINVAL, "null pointer");
+  return x->dtype == DQL_F32 ? get_obs_t<float>(x, out) : get_obs_t<double>(x, out);
+}
+
+// ---- tables ----
+int dql_get_tables(dql_ctx* x, double* qa, double* qb, double* count) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  if (qa) HIP_TRY(hipMemcpyAsync(qa, x->qa, B, hipMemcpyDeviceToHost, x->stream));
+  if (qb) HIP_TRY(hipMemcpyAsync(qb, x->qb, B, hipMemcpyDeviceToHost, x->stream));
+  if (count) HIP_TRY(hipMemcpyAsync(count, x->count, B, hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+int dql_set_tables(dql_ctx* x, const double* qa, const double* qb, const double* count) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  if (qa) { HIP_TRY(hipMemcpyAsync(x->qa, qa, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->qa_base, qa, B, hipMemcpyHostToDevice, x->stream)); }
+  if (qb) HIP_TRY(hipMemcpyAsync(x->qb, qb, B, hipMemcpyHostToDevice, x->stream));
+  if (count) { HIP_TRY(hipMemcpyAsync(x->count, count, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->count_base, count, B, hipMemcpyHostToDevice, x->stream)); }
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+int dql_transfer(dql_ctx* x, int32_t k, double ratio) {
+  CHECK_CTX(x);
+  if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
+  HIP_TRY(hipSetDevice(x->device));
+  const int src = (k - 1 + DQL_MAX_LEVELS) % DQL_MAX_LEVELS;  // k = 0 wraps to the last level (B6)
+  hipLaunchKernelGGL(k_transfer, dim3((DQL_CELLS_PER_LEVEL + 255) / 256), dim3(256), 0, x->stream, x->qa, x->qb, k, src, ratio);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+  return DQL_OK;
+}
+
+// ---- multi-GPU exchange ----
+int dql_set_sync_period(dql_ctx* x, int32_t k) {
+  CHECK_CTX(x);
+  if (k < 1) return fail(DQL_EINVAL, "sync period must be >= 1");
+  x->sync_period = k;
+  return DQL_OK;
+}
+int dql_set_windowed(dql_ctx* x, int32_t on) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  if (on && !x->windowed) {
+    HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+    HIP_TRY(hipMemcpyAsync(x->count_base, x->count, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+    HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  }
+  x->windowed = on != 0;
+  return DQL_OK;
+}
+int dql_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
+  CHECK_CTX(x);
+  if (dev_ptr) *dev_ptr = x->window;
+  if (n_int64) *n_int64 = 2 * DQL_N_CELLS;
+  return DQL_OK;
+}
+int dql_stream_handle(dql_ctx* x, void** s) { CHECK_CTX(x); if (s) *s = (void*)x->stream; return DQL_OK; }
+int dql_apply_accum(dql_ctx* x) {
+  CHECK_CTX(x);
+  if (!x->windowed) return fail(DQL_ESTATE, "dql_apply_accum needs windowed accumulation (dql_set_windowed)");
+  HIP_TRY(hipSetDevice(x->device));
+  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->window, x->alpha_tab, x->n_tab, x->cfg.alpha_min};
+  hipLaunchKernelGGL(k_apply_window, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, a);
+  HIP_TRY(hipGetLastError());
+  return DQL_OK;
+}
+int dql_get_accum(dql_ctx* x, int64_t* out) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(out, x->window, 2 * DQL_N_CELLS * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+int dql_set_accum(dql_ctx* x, const int64_t* in) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemcpyAsync(x->window, in, 2 * DQL_N_CELLS * sizeof(long long), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return DQL_OK;
+}
+
+// ---- stats / timing / knobs ----
+int dql_stats_get(dql_ctx* x, dql_stats* out) {
+  CHECK_CTX(x);
+  if (!out) return fail(DQL_EINVAL, "null pointer");
+  HIP_TRY(hipSetDevice(x->device));
+  StatsDev s; Sched sc;
+  HIP_TRY(hipMemcpyAsync(&s, x->stats, sizeof(s), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipMemcpyAsync(&sc, x->sched, sizeof(sc), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  out->agent_steps = (int64_t)s.agent_steps; out->decisions = (int64_t)s.decisions; out->episodes = (int64_t)s.episodes;
+  for (int k = 0; k < DQL_N_CHECK_CODES; ++k) out->by_code[k] = (int64_t)s.by_code[k];
+  out->reward_sum = (double)s.reward_fx / (double)(1ll << DQL_TARGET_FRAC_BITS);
+  out->physics_ticks = sc.g0;
+  return DQL_OK;
+}
+int dql_stats_reset(dql_ctx* x) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream));
+  return DQL_OK;
+}
+int dql_timer_start(dql_ctx* x) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  x->timer_launches = 0;
+  HIP_TRY(hipEventRecord(x->ev0, x->stream));
+  return DQL_OK;
+}
+int dql_timer_stop(dql_ctx* x, double* ms) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipEventRecord(x->ev1, x->stream));
+  HIP_TRY(hipEventSynchronize(x->ev1));
+  float f = 0;
+  HIP_TRY(hipEventElapsedTime(&f, x->ev0, x->ev1));
+  if (ms) *ms = (double)f;
+  return DQL_OK;
+}
+int dql_kernel_timer(dql_ctx* x, int32_t on) {
+  CHECK_CTX(x);
+  for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
+  x->kev.clear();
+  x->kernel_timer = on != 0;
+  return DQL_OK;
+}
+int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  double tot = 0; int64_t n = 0;
+  for (size_t i = 0; i + 1 < x->kev.size(); i += 2) { float f = 0; HIP_TRY(hipEventElapsedTime(&f, x->kev[i], x->kev[i + 1])); tot += f; ++n; }
+  if (avg_ms) *avg_ms = n ? tot / (double)n : 0.0;
+  if (launches) *launches = n;
+  return DQL_OK;
+}
+int dql_use_graph(dql_ctx* x, int32_t enable) { CHECK_CTX(x); x->use_graph = enable != 0; return DQL_OK; }
+int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
+  CHECK_CTX(x);
+  if (!name) return fail(DQL_EINVAL, "null option name");
+  if (!strcmp(name, "lds_tables")) { x->lds_tables = value != 0; return DQL_OK; }
+  if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(DQL_EINVAL, "block must be 0, 64, 128 or 256"); x->block = value; return DQL_OK; }
+  return fail(DQL_EINVAL, std::string("unknown option ") + name);
+}
+
+// ---- stateless operators ----
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t b) { hipError_t e = hipMalloc(&p, b ? b : 1); return e == hipSuccess ? 0 : -1; }
+};
+#define OP_PROLOGUE(device)                                                                \
+  int _ndev = 0;                                                                           \
+  HIP_TRY(hipGetDeviceCount(&_ndev));                                                      \
+  if (_ndev < 1) return fail(DQL_EHIP, "no HIP device visible (there is no CPU fallback)"); \
+  if ((device) < 0 || (device) >= _ndev) return fail(DQL_EINVAL, "device index out of range"); \
+  HIP_TRY(hipSetDevice(device));
+#define UP(buf, host, bytes) do { if ((buf).alloc(bytes)) return fail(DQL_ENOMEM, "hipMalloc failed"); HIP_TRY(hipMemcpy((buf).p, (host), (bytes), hipMemcpyHostToDevice)); } while (0)
+
+int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const double* rel_v, const double* rel_a, const double* angle, int64_t n, int32_t* idx_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 0 && (!rel_p || !rel_v || !rel_a || !angle || !idx_out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf p, v, a, t, o;
+  const size_t B = (size_t)n * sizeof(double);
+  UP(p, rel_p, B); UP(v, rel_v, B); UP(a, rel_a, B); UP(t, angle, B);
+  if (o.alloc((size_t)n * sizeof(int))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_discretise<float>, dim3(grid), dim3(256), 0, 0, make_devc<float>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
+  else hipLaunchKernelGGL(k_discretise<double>, dim3(grid), dim3(256), 0, 0, make_devc<double>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(idx_out, o.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, const uint8_t* action, const double* obs, double* mdp_state, const int32_t* prev_idx,
+                       int32_t* idx_out, double* reward_out, uint8_t* done_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 0 && (!action || !obs || !mdp_state || !prev_idx || !idx_out || !reward_out || !done_out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  for (int64_t i = 0; i < n; ++i) if (action[i] > 2) return fail(DQL_EINVAL, "action must be 0, 1 or 2");
+  OP_PROLOGUE(device)
+  DevBuf a, o, ms, pi, io, ro, dn;
+  UP(a, action, (size_t)n); UP(o, obs, (size_t)n * 7 * sizeof(double)); UP(ms, mdp_state, (size_t)n * 8 * sizeof(double)); UP(pi, prev_idx, (size_t)n * sizeof(int));
+  if (io.alloc((size_t)n * sizeof(int)) || ro.alloc((size_t)n * sizeof(double)) || dn.alloc((size_t)n)) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_mdp_transition<float>, dim3(grid), dim3(256), 0, 0, make_devc<float>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  else hipLaunchKernelGGL(k_mdp_transition<double>, dim3(grid), dim3(256), 0, 0, make_devc<double>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mdp_state, ms.p, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(idx_out, io.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(reward_out, ro.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(done_out, dn.p, (size_t)n, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out) {
+  if (n < 0 || !qa || !qb || (n > 0 && (!idx || !action_out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  for (int64_t i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "state index out of range");
+  OP_PROLOGUE(device)
+  DevBuf a, b, ix, o;
+  UP(a, qa, DQL_N_CELLS * sizeof(double)); UP(b, qb, DQL_N_CELLS * sizeof(double)); UP(ix, idx, (size_t)n * sizeof(int));
+  if (o.alloc((size_t)n)) return fail(DQL_ENOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_predict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double*)a.p, (const double*)b.p, (const int*)ix.p, (long long)n, (uint8_t*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(action_out, o.p, (size_t)n, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_agent_update(int device, double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma,
+                     const double* reward, int64_t n, uint32_t quirks) {
+  if (n < 0 || !qa || !qb || !count || (n > 0 && (!sa || !ns || !alpha || !reward))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  for (int64_t i = 0; i < n; ++i) if (sa[i] < 0 || sa[i] >= DQL_N_CELLS || ns[i] < 0 || ns[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "index out of range");
+  OP_PROLOGUE(device)
+  DevBuf a, b, c, s, t, al, rw;
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  UP(a, qa, B); UP(b, qb, B); UP(c, count, B); UP(s, sa, (size_t)n * sizeof(int)); UP(t, ns, (size_t)n * sizeof(int)); UP(al, alpha, (size_t)n * sizeof(double)); UP(rw, reward, (size_t)n * sizeof(double));
+  hipLaunchKernelGGL(k_update_seq, dim3(1), dim3(64), 0, 0, (double*)a.p, (double*)b.p, (double*)c.p, (const int*)s.p, (const int*)t.p, (const double*)al.p, gamma, (const double*)rw.p, (long long)n, quirks);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(qa, a.p, B, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(qb, b.p, B, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(count, c.p, B, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+"""`Engine`: one GPU's shard of vectorised landing environments + the Q tables, over the C ABI.
+
+This is the vectorised counterpart of `gym.make("Landing-Training-v0")` + `DoubleQLearningAgent()` in the
+reference's trainer (pkg/trainer.py:46-48,176-183): `train_steps` is the loop body of pkg/trainer.py:191-212 for
+all envs at once.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import CHECK_NAMES, DqlConfig, N_CELLS, TABLE_SHAPE
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, cfg: DqlConfig, n_envs: int, seed: int = 42, device: int = 0, env_id_offset: int = 0, alpha_table=None):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.n = int(n_envs)
+        self._c = cfg.to_c()
+        h = C.c_void_p()
+        _lib.check(self.lib.dql_create(C.byref(self._c), device, self.n, seed, env_id_offset, C.byref(h)))
+        self._h = h
+        tab = cfg.alpha_table() if alpha_table is None else np.ascontiguousarray(alpha_table, dtype=np.float64)
+        _lib.check(self.lib.dql_set_alpha_table(self._h, _p(tab), len(tab)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dql_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stepping ----
+    def train_steps(self, n_steps: int, eps: float):
+        _lib.check(self.lib.dql_train_steps(self._h, int(n_steps), float(eps)))
+
+    def eval_steps(self, n_steps: int):
+        _lib.check(self.lib.dql_eval_steps(self._h, int(n_steps)))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.uint8)
+        if a.shape != (self.n,):
+            raise ValueError(f"actions must have shape ({self.n},)")
+        if (a > 2).any():
+            raise ValueError("actions must be 0, 1 or 2")
+        _lib.check(self.lib.dql_step(self._h, _p(a)))
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _lib.check(self.lib.dql_reset(self._h, _p(m)))
+
+    def set_curriculum(self, level: int):
+        _lib.check(self.lib.dql_set_curriculum(self._h, int(level)))
+        self.cfg.working_curriculum_step = int(level)
+
+    def sync(self):
+        _lib.check(self.lib.dql_sync(self._h))
+
+    # ---- per-env results ----
+    def states(self):
+        idx = np.zeros(self.n, dtype=np.int32)
+        _lib.check(self.lib.dql_get_states(self._h, _p(idx), None))
+        return idx
+
+    def rewards(self):
+        r = np.zeros(self.n, dtype=np.float64)
+        _lib.check(self.lib.dql_get_rewards(self._h, _p(r)))
+        return r
+
+    def dones(self):
+        d = np.zeros(self.n, dtype=np.uint8); c = np.zeros(self.n, dtype=np.int8)
+        _lib.check(self.lib.dql_get_dones(self._h, _p(d), _p(c)))
+        return d, c
+
+    def actions(self):
+        a = np.zeros(self.n, dtype=np.uint8)
+        _lib.check(self.lib.dql_get_actions(self._h, _p(a)))
+        return a
+
+    def obs(self):
+        o = np.zeros((6, self.n), dtype=np.float64)
+        _lib.check(self.lib.dql_get_obs(self._h, _p(o)))
+        return o
+
+    def n_fields(self):
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dql_n_fields(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def field_names(self, is_int=False):
+        n = self.n_fields()[1 if is_int else 0]
+        return [self.lib.dql_field_name(i, int(is_int)).decode() for i in range(n)]
+
+    def get_fields(self):
+        nr, ni = self.n_fields()
+        reals = np.zeros((nr, self.n), dtype=np.float64); ints = np.zeros((ni, self.n), dtype=np.int32)
+        _lib.check(self.lib.dql_get_sim_state(self._h, _p(reals), nr))
+        _lib.check(self.lib.dql_get_sim_ints(self._h, _p(ints), ni))
+        return reals, ints
+
+    def set_fields(self, reals, ints):
+        reals = np.ascontiguousarray(reals, dtype=np.float64); ints = np.ascontiguousarray(ints, dtype=np.int32)
+        _lib.check(self.lib.dql_set_sim_state(self._h, _p(reals), reals.shape[0]))
+        _lib.check(self.lib.dql_set_sim_ints(self._h, _p(ints), ints.shape[0]))
+
+    # ---- tables ----
+    def get_tables(self):
+        qa = np.zeros(N_CELLS); qb = np.zeros(N_CELLS); cnt = np.zeros(N_CELLS)
+        _lib.check(self.lib.dql_get_tables(self._h, _p(qa), _p(qb), _p(cnt)))
+        return qa.reshape(TABLE_SHAPE), qb.reshape(TABLE_SHAPE), cnt.reshape(TABLE_SHAPE)
+
+    def set_tables(self, qa=None, qb=None, count=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ravel()
+        qa, qb, count = f(qa), f(qb), f(count)
+        for a in (qa, qb, count):
+            if a is not None and a.size != N_CELLS:
+                raise ValueError(f"tables must have shape {TABLE_SHAPE}")
+        _lib.check(self.lib.dql_set_tables(self._h, _p(qa), _p(qb), _p(count)))
+
+    def transfer(self, k: int, ratio: float):
+        _lib.check(self.lib.dql_transfer(self._h, int(k), float(ratio)))
+
+    # ---- multi-GPU exchange ----
+    def set_windowed(self, on: bool):
+        _lib.check(self.lib.dql_set_windowed(self._h, int(on)))
+
+    def accum_dev_ptr(self):
+        p = C.c_void_p(); n = C.c_int64()
+        _lib.check(self.lib.dql_accum_dev_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream_handle(self):
+        p = C.c_void_p()
+        _lib.check(self.lib.dql_stream_handle(self._h, C.byref(p)))
+        return p.value
+
+    def apply_accum(self):
+        _lib.check(self.lib.dql_apply_accum(self._h))
+
+    def get_accum(self):
+        a = np.zeros(2 * N_CELLS, dtype=np.int64)
+        _lib.check(self.lib.dql_get_accum(self._h, _p(a)))
+        return a
+
+    def set_accum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        _lib.check(self.lib.dql_set_accum(self._h, _p(a)))
+
+    # ---- stats / timing / knobs ----
+    def stats(self):
+        s = _lib.DqlStatsC()
+        _lib.check(self.lib.dql_stats_get(self._h, C.byref(s)))
+        return {"agent_steps": s.agent_steps, "decisions": s.decisions, "episodes": s.episodes,
+                "by_code": {CHECK_NAMES[i]: s.by_code[i] for i in range(len(CHECK_NAMES))},
+                "reward_sum": s.reward_sum, "physics_ticks": s.physics_ticks}
+
+    def stats_reset(self):
+        _lib.check(self.lib.dql_stats_reset(self._h))
+
+    def timer_start(self):
+        _lib.check(self.lib.dql_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        _lib.check(self.lib.dql_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_timer(self, on: bool):
+        _lib.check(self.lib.dql_kernel_timer(self._h, int(on)))
+
+    def kernel_time_ms(self):
+        ms = C.c_double(); n = C.c_int64()
+        _lib.check(self.lib.dql_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_option(self, name: str, value: int):
+        _lib.check(self.lib.dql_set_option(self._h, name.encode(), int(value)))
+
+    def state_bytes_per_env(self) -> int:
+        b = C.c_int64()
+        _lib.check(self.lib.dql_state_bytes_per_env(self._h, C.byref(b)))
+        return b.value

@@ -1,0 +1,59 @@
+"""Stateless batch operators of the C ABI (computed on the device): the arithmetic behind the drop-in
+`TrainingMdp` / `DoubleQLearningAgent` methods."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import DqlConfig, Q_REFERENCE
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def discretise(cfg: DqlConfig, rel_p, rel_v, rel_a, angle, device: int = 0) -> np.ndarray:
+    """TrainingMdp.discrete_state (pkg/mdp.py:257-333) for n observations -> packed indices (-1 where the reference raises)."""
+    p, v, a, t = map(_f64, (rel_p, rel_v, rel_a, angle))
+    if not (p.shape == v.shape == a.shape == t.shape and p.ndim == 1):
+        raise ValueError("inputs must be 1-D arrays of equal length")
+    out = np.zeros(len(p), dtype=np.int32)
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_discretise(C.byref(c), device, _p(p), _p(v), _p(a), _p(t), len(p), _p(out)))
+    return out
+
+
+def mdp_transition(cfg: DqlConfig, action, obs, mdp_state, prev_idx, device: int = 0):
+    n = len(action)
+    action = np.ascontiguousarray(action, dtype=np.uint8)
+    obs = _f64(obs); ms = _f64(mdp_state).copy(); prev_idx = np.ascontiguousarray(prev_idx, dtype=np.int32)
+    if obs.shape != (7, n) or ms.shape != (8, n) or prev_idx.shape != (n,):
+        raise ValueError("obs must be [7][n], mdp_state [8][n], prev_idx [n]")
+    idx = np.zeros(n, dtype=np.int32); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_mdp_transition(C.byref(c), device, n, _p(action), _p(obs), _p(ms), _p(prev_idx), _p(idx), _p(rew), _p(done)))
+    return ms, idx, rew, done
+
+
+def agent_predict(qa, qb, idx, device: int = 0) -> np.ndarray:
+    qa, qb = _f64(qa).ravel(), _f64(qb).ravel()
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros(len(idx), dtype=np.uint8)
+    _lib.check(_lib.load().dql_agent_predict(device, _p(qa), _p(qb), _p(idx), len(idx), _p(out)))
+    return out
+
+
+def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks: int = Q_REFERENCE, device: int = 0):
+    """In-place ordered replay of DoubleQLearningAgent.update; qa/qb/count must be contiguous float64 of 2835 cells."""
+    for t in (qa, qb, count):
+        if t.dtype != np.float64 or not t.flags.c_contiguous or t.size != 2835:
+            raise ValueError("tables must be contiguous float64 arrays of 2835 cells")
+    sa = np.ascontiguousarray(sa, dtype=np.int32); ns = np.ascontiguousarray(ns, dtype=np.int32)
+    alpha = _f64(alpha); reward = _f64(reward)
+    _lib.check(_lib.load().dql_agent_update(device, _p(qa), _p(qb), _p(count), _p(sa), _p(ns), _p(alpha), float(gamma), _p(reward), len(sa), quirks))

@@ -177,6 +177,9 @@ int dql_transfer(dql_ctx* ctx, int32_t k, double ratio); /* transfer_learning (p
 
 /* ---- multi-GPU exchange: int64 accumulators [2][2835] = {sum of targets (fixed point), visits} ---- */
 int dql_set_sync_period(dql_ctx* ctx, int32_t k_steps); /* 1 = apply every step (single-GPU semantics) */
+/* windowed accumulation: every step also adds its accumulators into the window buffer and updates only the local
+ * work tables; dql_apply_accum folds the (all-reduced) window into the base tables and re-bases the work tables */
+int dql_set_windowed(dql_ctx* ctx, int32_t on);
 int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device buffer to all-reduce (sum) */
 int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
 int dql_apply_accum(dql_ctx* ctx); /* apply the (all-reduced) accumulators to the base tables, clear them */
@@ -188,9 +191,12 @@ int dql_stats_get(dql_ctx* ctx, dql_stats* out);
 int dql_stats_reset(dql_ctx* ctx);
 int dql_timer_start(dql_ctx* ctx); /* hipEventRecord on the ctx stream */
 int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, returns elapsed */
-/* average device duration of the fused step kernel over the launches since timer_start (per-launch events) */
+/* average device duration of the fused step kernel over the launches made while the kernel timer was armed */
 int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
+int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
 int dql_use_graph(dql_ctx* ctx, int32_t enable);
+/* tuning knobs: "lds_tables" (0/1: stage the Q tables in LDS), "block" (0 = auto, 64, 128, 256 threads per workgroup) */
+int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 
 /* ---- stateless batch operators (host arrays in/out, computed on the device; drop-in class methods) ---- */
 /* TrainingMdp.discrete_state (pkg/mdp.py:257-333): 4 x double[n] -> packed idx int32[n]; -1 where the reference raises */

@@ -422,7 +422,7 @@ typedef struct {
   pidc_t pvz, pyaw; bwc_t bw;
   REAL mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma, p_max;
   REAL noise_p, noise_v, kal_q, kal_r, mgr_dt;
-  int div, traj, init_uniform, working, per_env_platform;
+  int div, traj, init_uniform, working, per_env_platform, two_axis;
   REAL mp_r, mp_w, mp_r_lo, mp_r_hi, mp_t_lo, mp_t_hi;
   uint32_t quirks;
 } simc_t;
@@ -445,7 +445,7 @@ static void simc_init(simc_t* s, const dql_config* c) {
   s->kal_r = (REAL)(c->noise_vel_sd * c->noise_vel_sd); /* pkg/filters.py:49 */
   s->mgr_dt = (REAL)(c->dt * c->manager_div);
   s->div = c->manager_div; s->traj = c->trajectory; s->init_uniform = c->init_uniform; s->working = c->working_curriculum_step;
-  s->per_env_platform = c->per_env_platform;
+  s->per_env_platform = c->per_env_platform; s->two_axis = c->two_axis;
   s->mp_r = (REAL)c->mp_r_x; s->mp_w = (REAL)(c->mp_t_x / c->mp_r_x);
   if (c->trajectory == DQL_TRAJ_EIGHT) { s->mp_r = R_(3.0); s->mp_w = (REAL)(0.8 / 3.0); } /* pkg/moving_platform.py:93-97 */
   s->mp_r_lo = (REAL)c->mp_r_lo; s->mp_r_hi = (REAL)c->mp_r_hi; s->mp_t_lo = (REAL)c->mp_t_lo; s->mp_t_hi = (REAL)c->mp_t_hi;
@@ -571,15 +571,15 @@ static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL
   }
   REAL ax_ = R_(0.0), ay_ = R_(0.0);
   if (!(e->flags & FL_ACC_INIT)) { /* pkg/observation_utils.py:137-143 */
-    e->vf[0] = rvx; e->vf[1] = rvy; e->flags |= FL_ACC_INIT;
+    e->vf[0] = rvx; if (s->two_axis) e->vf[1] = rvy; e->flags |= FL_ACC_INIT;
   } else {
     REAL dt_;
     if (s->quirks & DQL_Q_FROZEN_ACC_REFERENCE) dt_ = (REAL)mgr_index * s->mgr_dt; /* time since the first sample; B19 */
     else dt_ = s->mgr_dt;
     if (dt_ <= R_(0.0)) dt_ = R_(0.01); /* pkg/filters.py:67-69 */
     ax_ = kalman1d(&e->kal_x[0], &e->kal_P[0], s->kal_q, s->kal_r, (rvx - e->vf[0]) / dt_);
-    ay_ = kalman1d(&e->kal_x[1], &e->kal_P[1], s->kal_q, s->kal_r, (rvy - e->vf[1]) / dt_);
-    if (!(s->quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e->vf[0] = rvx; e->vf[1] = rvy; }
+    if (s->two_axis) ay_ = kalman1d(&e->kal_x[1], &e->kal_P[1], s->kal_q, s->kal_r, (rvy - e->vf[1]) / dt_); /* y estimator only flies in 2-axis configs */
+    if (!(s->quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e->vf[0] = rvx; if (s->two_axis) e->vf[1] = rvy; }
   }
   e->obs[0] = opx; e->obs[1] = opy; e->obs[2] = ovx; e->obs[3] = ovy; e->obs[4] = ax_; e->obs[5] = ay_;
   /* Observation.contact = the latched bumper flag at publish time (pkg/observation_utils.py:156) */
