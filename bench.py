@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the fused UAV-landing + tabular Double-Q training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--envs E] [--dtype f32|f64] [--sync-period S]
+
+One "step" = one agent period (1/22.92 s of simulated time: 21-22 physics ticks + MDP + TD update) for every env of
+every rank.  Workload at N=1: BASELINE.json configs[1] — 4096 vectorised envs, x-axis MDP, curriculum step 0, eps 1.0,
+state resident in HBM before the timed region.  N>1 (launched by torch.distributed.run): weak scaling, E envs per GPU,
+env shards with global env ids, int64 accumulator all-reduce (RCCL) every --sync-period steps.
+`value` counts env-steps = (env, period) pairs in which an action was taken (reset periods are not counted).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALGO_BYTES_PER_ENV_STEP = 320  # 40 four-byte words of persistent per-env state, read once + written once
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(envs: int, steps: int, dtype: int):
+    """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on ONE host core, bounded sample."""
+    from dql_multirotor_landing_amd.config import DqlConfig
+    from oracle.oracle import Oracle
+    o = Oracle(DqlConfig(dtype=dtype), envs, seed=42)
+    o.train_steps(3, 1.0)
+    d0 = o.stats_dict()["decisions"]
+    t0 = time.perf_counter()
+    o.train_steps(steps, 1.0)
+    dt = time.perf_counter() - t0
+    d = o.stats_dict()["decisions"] - d0
+    return {"value": d / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{envs} envs x {steps} agent periods ({d} env-steps, {dt:.1f} s), single thread, same dtype, gcc -O2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--eps", type=float, default=1.0)
+    ap.add_argument("--sync-period", type=int, default=32)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--lds-tables", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=60)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime (same SONAME as /opt/rocm's) must be the one the process binds
+        import torch
+        import torch.distributed as dist
+    import __graft_entry__ as g
+    g.build_hip()
+    from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
+    from dql_multirotor_landing_amd.dist import ShardedRunner, TorchWindowReducer
+    from dql_multirotor_landing_amd.engine import Engine
+
+    dtype = F32 if args.dtype == "f32" else F64
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0)
+    eng = Engine(cfg, args.envs, seed=42, device=local_rank if world > 1 else 0, env_id_offset=rank * args.envs)
+    eng.set_option("block", args.block)
+    eng.set_option("lds_tables", args.lds_tables)
+    reducer = TorchWindowReducer(eng, local_rank) if world > 1 else None
+    runner = ShardedRunner(eng, reducer, sync_period=args.sync_period)
+
+    def barrier():
+        eng.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    runner.train_steps(args.warmup, args.eps)
+    runner.sync()
+    barrier()
+    s0 = eng.stats()
+    eng.timer_start()
+    t0 = time.perf_counter()
+    runner.train_steps(args.steps, args.eps)
+    runner.sync()
+    dev_ms = eng.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    s1 = eng.stats()
+    decisions = s1["decisions"] - s0["decisions"]
+
+    # per-launch duration of the fused step kernel, HIP events on the engine's stream (separate short pass)
+    eng.kernel_timer(True)
+    eng.train_steps(min(200, max(20, args.steps // 10)), args.eps)
+    k_ms, k_n = eng.kernel_time_ms()
+    eng.kernel_timer(False)
+    s2 = eng.stats()
+    dec_per_launch = (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])
+
+    if world > 1:
+        t = torch.tensor([wall, float(decisions)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0]); decisions = int(tsum[1])
+
+    if rank == 0:
+        value = decisions / wall
+        ach = ALGO_BYTES_PER_ENV_STEP * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.envs} vectorised envs per GPU, x-axis MDP, curriculum step 0, eps {args.eps}, "
+                                   f"rpm platform r=2 m omega=0.8 rad/s, fused step kernel + int64 LDS/global accumulators",
+                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
+                       "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables},
+            "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": dec_per_launch,
+                         "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
+            "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

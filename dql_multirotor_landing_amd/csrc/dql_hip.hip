@@ -303,7 +303,7 @@ struct dql_ctx {
   int4* si = nullptr;
   double *qa = nullptr, *qb = nullptr, *count = nullptr;          // work tables
   double *qa_base = nullptr, *count_base = nullptr;               // multi-GPU base tables
-  long long *accum = nullptr, *window = nullptr;
+  long long *accum = nullptr, *window = nullptr, *window_own = nullptr;
   double* alpha_tab = nullptr; int n_tab = 0;
   Sched* sched = nullptr; StatsDev* stats = nullptr;
   uint8_t* d_actions = nullptr;
@@ -491,7 +491,7 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   ALLOC(x->si, (size_t)x->n * sizeof(int4));
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
   ALLOC(x->qa_base, DQL_N_CELLS * sizeof(double)); ALLOC(x->count_base, DQL_N_CELLS * sizeof(double));
-  ALLOC(x->accum, 2 * DQL_N_CELLS * sizeof(long long)); ALLOC(x->window, 2 * DQL_N_CELLS * sizeof(long long));
+  ALLOC(x->accum, 2 * DQL_N_CELLS * sizeof(long long)); ALLOC(x->window_own, 2 * DQL_N_CELLS * sizeof(long long)); x->window = x->window_own;
   ALLOC(x->sched, sizeof(Sched)); ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n);
 #undef ALLOC
   HIP_TRY(hipMemsetAsync(x->sr, 0, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size, x->stream));
@@ -517,7 +517,7 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window, x->alpha_tab, x->sched, x->stats, x->d_actions};
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window_own, x->alpha_tab, x->sched, x->stats, x->d_actions};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -732,6 +732,15 @@ int dql_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
   CHECK_CTX(x);
   if (dev_ptr) *dev_ptr = x->window;
   if (n_int64) *n_int64 = 2 * DQL_N_CELLS;
+  return DQL_OK;
+}
+int dql_set_window_buffer(dql_ctx* x, void* dev_ptr) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  x->window = dev_ptr ? (long long*)dev_ptr : x->window_own;
+  HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }
 int dql_stream_handle(dql_ctx* x, void** s) { CHECK_CTX(x); if (s) *s = (void*)x->stream; return DQL_OK; }

@@ -1,0 +1,85 @@
+"""Multi-GPU exchange: envs shard across ranks with no data-path collective; the only exchange is
+the periodic sum of the int64 window accumulators [2][2835] = {fixed-point TD-target sums, visit counts}, after
+which every rank folds the same totals into its base tables (bit-identical replicas, independent of the order of
+summation).  One process per GPU; `torch.distributed` (backend "nccl" = RCCL over xGMI) is plumbing only: it
+owns the 45 KB exchange buffer and runs the all-reduce on the engine's HIP stream.
+
+`ShardedRunner` is backend-agnostic: the engine is anything with train_steps / apply_accum / window access (the HIP
+`Engine` in production; CPU tests inject a stand-in to exercise sharding + reduction with the gloo backend)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .config import N_CELLS
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous env-id range of `rank`; the ids key the per-env RNG, so results do not depend on `world`."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class TorchWindowReducer:
+    """All-reduce(sum) of the engine's window accumulators with torch.distributed on the engine's stream."""
+
+    def __init__(self, engine, device_index: int, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.engine = engine
+        dev = torch.device("cuda", device_index)
+        self.buf = torch.zeros(2 * N_CELLS, dtype=torch.int64, device=dev)
+        engine.set_window_buffer(self.buf.data_ptr())
+        self.stream = torch.cuda.ExternalStream(engine.stream_handle(), device=dev)
+
+    def all_reduce(self):
+        with self.torch.cuda.stream(self.stream):
+            self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class HostWindowReducer:
+    """Same exchange through host memory (gloo): used by the CPU tests and as a debugging aid."""
+
+    def __init__(self, engine, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.engine = torch, dist, group, engine
+
+    def all_reduce(self):
+        t = self.torch.from_numpy(np.ascontiguousarray(self.engine.get_accum()))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.engine.set_accum(t.numpy())
+
+
+class ShardedRunner:
+    """Runs `n_steps` agent periods on this rank's shard and synchronises the tables every `sync_period` periods."""
+
+    def __init__(self, engine, reducer: Optional[object], sync_period: int = 1):
+        if sync_period < 1:
+            raise ValueError("sync_period must be >= 1")
+        self.engine, self.reducer, self.sync_period = engine, reducer, int(sync_period)
+        self._since = 0
+        if reducer is not None:
+            engine.set_windowed(True)
+
+    def train_steps(self, n_steps: int, eps: float):
+        if self.reducer is None:
+            self.engine.train_steps(n_steps, eps)
+            return
+        left = int(n_steps)
+        while left > 0:
+            k = min(left, self.sync_period - self._since)
+            self.engine.train_steps(k, eps)
+            self._since += k
+            left -= k
+            if self._since == self.sync_period:
+                self.sync()
+
+    def sync(self):
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+            self.engine.apply_accum()
+        self._since = 0

@@ -140,6 +140,9 @@ class Engine:
         _lib.check(self.lib.dql_accum_dev_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def set_window_buffer(self, dev_ptr):
+        _lib.check(self.lib.dql_set_window_buffer(self._h, C.c_void_p(dev_ptr) if dev_ptr else None))
+
     def stream_handle(self):
         p = C.c_void_p()
         _lib.check(self.lib.dql_stream_handle(self._h, C.byref(p)))

@@ -181,6 +181,9 @@ int dql_set_sync_period(dql_ctx* ctx, int32_t k_steps); /* 1 = apply every step 
  * work tables; dql_apply_accum folds the (all-reduced) window into the base tables and re-bases the work tables */
 int dql_set_windowed(dql_ctx* ctx, int32_t on);
 int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device buffer to all-reduce (sum) */
+/* use a caller-owned device buffer of 2*2835 int64 as the window (e.g. a torch tensor handed to torch.distributed);
+ * NULL restores the context's own buffer.  The buffer is zeroed; the context never frees it. */
+int dql_set_window_buffer(dql_ctx* ctx, void* dev_ptr);
 int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
 int dql_apply_accum(dql_ctx* ctx); /* apply the (all-reduced) accumulators to the base tables, clear them */
 int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy, for tests */

@@ -68,8 +68,7 @@ class Oracle:
         self.stats = np.zeros(12, dtype=np.int64)
         self.alpha_tab = cfg.alpha_table() if alpha_tab is None else _f64(alpha_tab)
         self.step_index = 0
-        self.sync_period = 1
-        self._since_sync = 0
+        self.windowed = False
         getattr(L, self.pfx + "init_envs")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), C.c_uint64(self.seed), C.c_int64(self.off))
 
     def _fn(self, name):
@@ -114,15 +113,34 @@ class Oracle:
                                    C.c_uint64(self.seed), C.c_int64(self.off), C.c_int64(j), C.c_int64(g0), C.c_int(n_ticks))
         self.step_index += 1
 
-    def apply_accum(self):
-        lib().orc_apply_accum(_p(self.qa), _p(self.count), _p(self.accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
+    def _contract(self, qa, count, accum):
+        lib().orc_apply_accum(_p(qa), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
                               C.c_double(self.cfg.alpha_min))
 
-    def train_steps(self, n_steps: int, eps: float, apply: bool = True):
+    # ---- windowed (multi-rank) semantics: same interface as the product Engine ----
+    def set_windowed(self, on: bool):
+        if on and not self.windowed:
+            self.qa_base = self.qa.copy(); self.count_base = self.count.copy()
+            self.window = np.zeros(2 * N_CELLS, dtype=np.int64)
+        self.windowed = bool(on)
+
+    def get_accum(self):
+        return self.window.copy()
+
+    def set_accum(self, a):
+        self.window[:] = a
+
+    def apply_accum(self):
+        """fold the (all-reduced) window into the base tables and re-base the work tables"""
+        self._contract(self.qa_base, self.count_base, self.window)
+        self.qa[:] = self.qa_base; self.count[:] = self.count_base
+
+    def train_steps(self, n_steps: int, eps: float):
         for _ in range(n_steps):
             self._period(0, eps)
-            if apply:
-                self.apply_accum()
+            if self.windowed:
+                self.window += self.accum
+            self._contract(self.qa, self.count, self.accum)
 
     def eval_steps(self, n_steps: int):
         for _ in range(n_steps):

@@ -140,3 +140,61 @@ def test_curriculum_switch_and_transfer(mods):
     eng.train_steps(30, 0.0); orc.train_steps(30, 0.0)
     _compare(eng, orc, exact=True, what="level 1")
     assert (eng.states() // 189).max() <= 1
+
+
+def test_windowed_accumulation_matches_oracle(mods):
+    """Multi-GPU semantics on one GPU: window accumulators, local work-table updates, fold into the base tables."""
+    Engine, Oracle = mods
+    n = 256
+    eng = Engine(DqlConfig(dtype=F32), n, seed=21)
+    orc = Oracle(DqlConfig(dtype=F32), n, seed=21)
+    eng.set_windowed(True); orc.set_windowed(True)
+    for _ in range(3):
+        eng.train_steps(8, 0.5); orc.train_steps(8, 0.5)
+        np.testing.assert_array_equal(eng.get_accum(), orc.get_accum())
+        _compare(eng, orc, exact=True, what="inside window")
+        eng.apply_accum(); orc.apply_accum()
+        assert not eng.get_accum().any()
+        _compare(eng, orc, exact=True, what="after fold")
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+import torch  # torch first: its bundled HIP runtime must be the one the process binds (same SONAME as /opt/rocm's)
+import torch.distributed as dist
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.dist import ShardedRunner, TorchWindowReducer
+from dql_multirotor_landing_amd.engine import Engine
+from oracle.oracle import Oracle
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+n = 512
+eng = Engine(DqlConfig(dtype=F32), n, seed=33)
+orc = Oracle(DqlConfig(dtype=F32), n, seed=33); orc.set_windowed(True)
+run = ShardedRunner(eng, TorchWindowReducer(eng, 0), sync_period=4)
+run.train_steps(12, 0.7)
+for _ in range(3):
+    orc.train_steps(4, 0.7); orc.apply_accum()
+eng.sync(); torch.cuda.synchronize()
+qa, qb, cnt = eng.get_tables()
+er, ei = eng.get_fields(); o_r, o_i = orc.get_fields()
+assert np.array_equal(qa.ravel(), orc.qa) and np.array_equal(cnt.ravel(), orc.count) and cnt.sum() > 0
+assert np.array_equal(ei, o_i) and np.array_equal(er, o_r)
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_reducer_world_size_1():
+    """The torch.distributed (RCCL) plumbing of the exchange on a single rank, in its own process (torch imported
+    before the HIP library): external window buffer owned by torch, all-reduce on the engine's stream, fold.  With one
+    rank the sum is the identity, so results equal the windowed oracle."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
