@@ -3,12 +3,13 @@ missing, or no MI355X is visible when a device call is made, this raises."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 from .config import DqlConfigC, N_CHECK_CODES
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC / "libdql_hip.so"
+LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
 OK, EINVAL, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4
 

@@ -164,20 +164,26 @@ template <typename T> DQL_DEV void box_muller(uint32_t ra, uint32_t rb, T& n0, T
 // constants (kernel argument, wave-uniform -> SGPRs).  Filled on the host by make_devc() with the same
 // double -> T casts the oracle uses.
 // ---------------------------------------------------------------------------------------------
-template <typename T> struct DevC {
-  // MDP
+// MdpK: used before / after the tick loop only; lives in device memory and is read with scalar loads AFTER the loop so
+// that its ~60 values never compete with the in-loop constants for SGPRs.
+template <typename T> struct MdpK {
   T p_max, v_max, a_max, theta_max, delta_theta, beta, sigma_a, min_alt;
   T w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   T lim_p[5], lim_v[5], lim_a[5], angles[7];
-  // simulator
+  double gamma;
+  int working;
+  uint32_t quirks;
+};
+// SimK: constants of the physics tick loop (kernel argument by value).
+template <typename T> struct SimK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, aup, adn, omax, cd, crd;
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
   T bw_k1, bw_k2, bw_inv;
-  T mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma;
+  T mp_dt, mp_top, mp_hx, mp_hy, bottom;
   T noise_p, noise_v, kal_q, kal_r, mgr_dt, mp_r, mp_w;
-  double gamma;
+  T p_max, theta_max, delta_theta, z_init, init_sigma;  // reset placement / set-point update (before the loop)
   int div, traj, init_uniform, working, per_env_platform, two_axis;
   uint32_t quirks;
 };
@@ -220,7 +226,7 @@ template <typename T> DQL_DEV int disc3(T v, T goal, T limit) {  // :160-170
   if (v <= limit) return 2;
   return -1;
 }
-template <typename T> DQL_DEV int discretise(const DevC<T>& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
+template <typename T> DQL_DEV int discretise(const MdpK<T>& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
   const T cp = clip(rel_p / m.p_max, T(-1.0), T(1.0));
   const T cv = clip(rel_v / m.v_max, T(-1.0), T(1.0));
   const T ca = clip(rel_a / m.a_max, T(-1.0), T(1.0));
@@ -247,13 +253,13 @@ DQL_DEV int idx_level(int idx) { return idx / DQL_STATES_PER_LEVEL; }
 DQL_DEV int idx_pos(int idx) { return (idx / 63) % 3; }
 DQL_DEV int idx_vel(int idx) { return (idx / 21) % 3; }
 
-template <typename T> DQL_DEV T continuous_action(const DevC<T>& m, T sp, int action) {  // :543-560
+template <typename T, typename K> DQL_DEV T continuous_action(const K& m, T sp, int action) {  // :543-560
   if (action == 0) { const T t = sp + m.delta_theta; return t < m.theta_max ? t : m.theta_max; }
   if (action == 1) { const T t = sp - m.delta_theta; return t > -m.theta_max ? t : -m.theta_max; }
   return sp;
 }
 template <typename T>
-DQL_DEV int mdp_check(const DevC<T>& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
+DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
                       T rel_p_y, T abs_p_z) {  // :335-439
   step_count += 1;
   if (!(m.quirks & DQL_Q_STICKY_CHECK)) code = DQL_NON_TERMINAL;
@@ -276,7 +282,7 @@ DQL_DEV int mdp_check(const DevC<T>& m, int& step_count, int& cur_check, int cod
   return code;
 }
 template <typename T>
-DQL_DEV T mdp_reward(const DevC<T>& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
+DQL_DEV T mdp_reward(const MdpK<T>& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
   const T ncp = clip(rel_p / m.p_max, T(-1.0), T(1.0));
   const T ncv = clip(rel_v / m.v_max, T(-1.0), T(1.0));
   const T npitch = angle_sp / m.theta_max;
@@ -315,14 +321,14 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // ---------------------------------------------------------------------------------------------
 // filters / PID  (pkg/filters.py, pkg/pid.py)
 // ---------------------------------------------------------------------------------------------
-template <typename T> DQL_DEV T butterworth(const DevC<T>& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
+template <typename T> DQL_DEV T butterworth(const SimK<T>& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
   const T value = c.bw_inv * (x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3 - (c.bw_k2 * y2));
   x2 = x1; x1 = x0;
   y3 = y2; y2 = y1; y1 = value;
   return value;
 }
 template <typename T>
-DQL_DEV T pid_output(const DevC<T>& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, T& integ, T& x1, T& x2, T& y1, T& y2, T& y3) {
+DQL_DEV T pid_output(const SimK<T>& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, T& integ, T& x1, T& x2, T& y1, T& y2, T& y3) {
   // pid.py:62-104 with Kd = 0 (launch/drone.launch:37,51; dql_create rejects Kd != 0)
   const T e0 = sp - state;
   integ = clip(integ + e0 * c.dt, -wind, wind);
@@ -355,7 +361,7 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
 }
 // attitude_controller.py:107-156
 template <typename T>
-DQL_DEV void attitude(const DevC<T>& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T r_cmd, T thrust, T (&cmd)[4]) {
+DQL_DEV void attitude(const SimK<T>& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T r_cmd, T thrust, T (&cmd)[4]) {
   T D[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { D[j] = fma_(cy, B[j], -(sy * B[3 + j])); D[3 + j] = fma_(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
@@ -373,7 +379,7 @@ DQL_DEV void attitude(const DevC<T>& s, const T (&R)[9], const T (&w)[3], const 
   for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
 }
 // gazebo_motor_model.cpp:434-500 + semi-implicit Euler of one rigid body
-template <typename T> DQL_DEV void motor_and_body(const DevC<T>& s, Env<T>& e, const T (&R)[9], const T (&cmd)[4]) {
+template <typename T> DQL_DEV void motor_and_body(const SimK<T>& s, Env<T>& e, const T (&R)[9], const T (&cmd)[4]) {
   const T l = s.l, h = s.h;
   const T w0 = e.w[0], w1 = e.w[1], w2 = e.w[2];
   const T T0 = s.kf * e.om[0] * e.om[0], T1 = s.kf * e.om[1] * e.om[1], T2 = s.kf * e.om[2] * e.om[2], T3 = s.kf * e.om[3] * e.om[3];
@@ -411,11 +417,12 @@ template <typename T> DQL_DEV void motor_and_body(const DevC<T>& s, Env<T>& e, c
   const T dyq = fma_(qw, e.w[1], fma_(qz, e.w[0], -(qx * e.w[2])));
   const T dzq = fma_(qw, e.w[2], fma_(qx, e.w[1], -(qy * e.w[0])));
   const T nw = fma_(hdt, dw, qw), nx = fma_(hdt, dxq, qx), ny = fma_(hdt, dyq, qy), nz = fma_(hdt, dzq, qz);
-  const T inv = T(1.0) / sqrt_(fma_(nw, nw, fma_(nx, nx, fma_(ny, ny, nz * nz))));
+  // renormalise with one Newton step of 1/sqrt(|q|^2) about 1: |q|^2 - 1 = O((dt |w|)^2), so the residual is O(dt^4)
+  const T inv = fma_(T(-0.5), fma_(nw, nw, fma_(nx, nx, fma_(ny, ny, nz * nz))), T(1.5));
   e.q[0] = nw * inv; e.q[1] = nx * inv; e.q[2] = ny * inv; e.q[3] = nz * inv;
 }
 // moving_platform.py:87-127
-template <typename T> DQL_DEV void platform_eval(const DevC<T>& s, Env<T>& e) {
+template <typename T> DQL_DEV void platform_eval(const SimK<T>& s, Env<T>& e) {
   T sn, cs;
   det_sincos(e.mp_phase, sn, cs);
   if (s.traj == DQL_TRAJ_EIGHT) {
@@ -426,7 +433,7 @@ template <typename T> DQL_DEV void platform_eval(const DevC<T>& s, Env<T>& e) {
     e.mp_u = e.mp_r * e.mp_w * cs; e.mp_v = T(0.0);
   }
 }
-template <typename T> DQL_DEV void platform_update(const DevC<T>& s, Env<T>& e) {
+template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e) {
   platform_eval(s, e);
   T ph = fma_(e.mp_w, s.mp_dt, e.mp_phase);
   if (ph >= T(6.28318530717958623200e+00)) ph -= T(6.28318530717958623200e+00);
@@ -434,7 +441,7 @@ template <typename T> DQL_DEV void platform_update(const DevC<T>& s, Env<T>& e) 
 }
 // manager_node.py:192-214 + observation_utils.py:77-158
 template <typename T>
-DQL_DEV void manager_tick(const DevC<T>& s, Env<T>& e, const T (&R)[9], T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
+DQL_DEV void manager_tick(const SimK<T>& s, Env<T>& e, const T (&R)[9], T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
                           uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step) {
   const T dxw = e.mp_x - e.p[0], dyw = e.mp_y - e.p[1];
   const T dvx = e.mp_u - e.v[0], dvy = e.mp_v - e.v[1];
@@ -479,8 +486,8 @@ struct StepOut {  // what one env contributes to the shared tables / counters th
 
 // One agent period of one env.  TabPtr: global or LDS pointer to the (read-only) Q tables.
 template <typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const DevC<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action, uint64_t seed,
-                             uint32_t env_id, long long step_index, long long g0, int n_ticks) {
+DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
+                             uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   StepOut out; out.cell = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.reward_fx = 0;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), step_lo = (uint32_t)step_index, step_hi = (uint32_t)((uint64_t)step_index >> 32);
   uint32_t r[4];
@@ -519,10 +526,12 @@ DQL_DEV StepOut agent_period(const DevC<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, 
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
+  int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
+  long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
   for (int i = 0; i < n_ticks; ++i) {
-    const long long g = g0 + i;
     quat_to_R(e.q, R); yaw_cs(R, cy, sy);
-    if (g % s.div == 0) { manager_tick(s, e, R, cy, sy, g / s.div, k0, k1, step_lo, step_hi, env_id, mgr_in_step); ++mgr_in_step; }
+    if (phase == 0) { manager_tick(s, e, R, cy, sy, mgr_index, k0, k1, step_lo, step_hi, env_id, mgr_in_step); ++mgr_in_step; ++mgr_index; }
+    phase = (phase + 1 == s.div) ? 0 : phase + 1;
     const T thrust = pid_output(s, s.vz_kp, s.vz_ki, s.vz_lo, s.vz_hi, s.vz_wind, s.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
     const T r_cmd = pid_output(s, s.yw_kp, s.yw_ki, s.yw_lo, s.yw_hi, s.yw_wind, s.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
@@ -531,17 +540,19 @@ DQL_DEV StepOut agent_period(const DevC<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, 
     e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
     if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
   }
+  asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the loop
+  const MdpK<T> m = *mp;
   quat_to_R(e.q, R);
   const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
   const T pitch = det_atan2(-R[6], cyy);
-  int idx = discretise(s, e.obs_px, e.obs_vx, e.obs_ax, pitch);
+  int idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
   if (idx < 0) idx = 0;
   e.idx_x = idx;
   e.reward = T(0.0);
   if (is_reset) return out;
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
-  e.code = mdp_check(s, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2]);
-  const T rew = mdp_reward(s, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
+  e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2]);
+  const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
   e.reward = rew;
   const bool done = e.code <= DQL_TERMINAL_TIMEOUT;
   if (done) e.flags |= FL_DONE;
@@ -554,7 +565,7 @@ DQL_DEV StepOut agent_period(const DevC<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, 
     int mask;
     if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
     else mask = !done;
-    const double target = (double)rew + (s.gamma * boot) * (double)mask;
+    const double target = (double)rew + (m.gamma * boot) * (double)mask;
     out.cell = prev_idx * 3 + action;
     out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
   }
@@ -567,7 +578,7 @@ DQL_DEV StepOut agent_period(const DevC<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, 
 // x-axis configs touch quads 0-10 (+13 when the platform is per-env) and write quad 14.
 // ---------------------------------------------------------------------------------------------
 template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict__ sr, const int4* __restrict__ si, long long n, long long i,
-                                            const DevC<T>& c) {
+                                            const SimK<T>& c) {
   const Quad<T> q0 = sr[0 * n + i], q1 = sr[1 * n + i], q2 = sr[2 * n + i], q3 = sr[3 * n + i], q4 = sr[4 * n + i], q5 = sr[5 * n + i];
   const Quad<T> q6 = sr[6 * n + i], q7 = sr[7 * n + i], q8 = sr[8 * n + i], q9 = sr[9 * n + i], q10 = sr[10 * n + i];
   const int4 iv = si[i];
@@ -593,7 +604,7 @@ template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict
   e.reward = T(0.0); e.obs_px = e.obs_vx = e.obs_ax = e.obs_py = e.obs_vy = e.obs_ay = T(0.0);
 }
 template <typename T> DQL_DEV void store_env(const Env<T>& e, Quad<T>* __restrict__ sr, int4* __restrict__ si, long long n, long long i,
-                                             const DevC<T>& c) {
+                                             const SimK<T>& c) {
   sr[0 * n + i] = Quad<T>{e.p[0], e.p[1], e.p[2], e.v[0]};
   sr[1 * n + i] = Quad<T>{e.v[1], e.v[2], e.q[0], e.q[1]};
   sr[2 * n + i] = Quad<T>{e.q[2], e.q[3], e.w[0], e.w[1]};

@@ -40,8 +40,8 @@ struct StatsDev { unsigned long long decisions, episodes, by_code[DQL_N_CHECK_CO
 // ---------------------------------------------------------------------------------------------
 // host -> device constants
 // ---------------------------------------------------------------------------------------------
-template <typename T> static DevC<T> make_devc(const dql_config& c) {
-  DevC<T> d;
+template <typename T> static MdpK<T> make_mdpk(const dql_config& c) {
+  MdpK<T> d;
   memset(&d, 0, sizeof(d));
   d.p_max = (T)c.p_max; d.v_max = (T)c.v_max; d.a_max = (T)c.a_max; d.theta_max = (T)c.theta_max; d.delta_theta = (T)c.delta_theta;
   d.beta = (T)c.beta; d.sigma_a = (T)c.sigma_a; d.min_alt = (T)c.minimum_altitude;
@@ -51,6 +51,12 @@ template <typename T> static DevC<T> make_devc(const dql_config& c) {
   const double step = (c.theta_max - (-c.theta_max)) / 6.0;  // np.linspace(-theta_max, theta_max, 7), pkg/mdp.py:145
   for (int i = 0; i < 6; ++i) d.angles[i] = (T)((double)i * step + (-c.theta_max));
   d.angles[6] = (T)c.theta_max;
+  d.gamma = c.gamma; d.working = c.working_curriculum_step; d.quirks = c.quirks;
+  return d;
+}
+template <typename T> static SimK<T> make_simk(const dql_config& c) {
+  SimK<T> d;
+  memset(&d, 0, sizeof(d));
   d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
   for (int i = 0; i < 3; ++i) { d.I[i] = (T)c.inertia[i]; d.inv_I[i] = (T)(1.0 / c.inertia[i]); d.kR[i] = (T)c.k_R[i]; d.kW[i] = (T)c.k_W[i]; }
   d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m;
@@ -61,12 +67,11 @@ template <typename T> static DevC<T> make_devc(const dql_config& c) {
   const double bc = c.bw_c, denom = 1 + bc * bc + 1.414 * bc;  // pkg/filters.py:94-106
   d.bw_inv = (T)(1.0 / denom); d.bw_k1 = (T)(bc * bc - 1.414 * bc + 1); d.bw_k2 = (T)(-2 * bc * bc + 2);
   d.mp_dt = (T)c.mp_dt; d.mp_top = (T)c.mp_top_z; d.mp_hx = (T)c.mp_half_x; d.mp_hy = (T)c.mp_half_y; d.bottom = (T)c.drone_bottom;
-  d.z_init = (T)c.z_init; d.init_sigma = (T)c.init_sigma;
   d.noise_p = (T)c.noise_pos_sd; d.noise_v = (T)c.noise_vel_sd; d.kal_q = (T)c.kalman_q; d.kal_r = (T)(c.noise_vel_sd * c.noise_vel_sd);
   d.mgr_dt = (T)(c.dt * c.manager_div);
   d.mp_r = (T)c.mp_r_x; d.mp_w = (T)(c.mp_t_x / c.mp_r_x);
   if (c.trajectory == DQL_TRAJ_EIGHT) { d.mp_r = (T)3.0; d.mp_w = (T)(0.8 / 3.0); }
-  d.gamma = c.gamma;
+  d.p_max = (T)c.p_max; d.theta_max = (T)c.theta_max; d.delta_theta = (T)c.delta_theta; d.z_init = (T)c.z_init; d.init_sigma = (T)c.init_sigma;
   d.div = c.manager_div; d.traj = c.trajectory; d.init_uniform = c.init_uniform; d.working = c.working_curriculum_step;
   d.per_env_platform = c.per_env_platform; d.two_axis = c.two_axis; d.quirks = c.quirks;
   return d;
@@ -76,13 +81,13 @@ template <typename T> static DevC<T> make_devc(const dql_config& c) {
 // kernels
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct InitArgs {
-  DevC<T> c; Quad<T>* sr; int4* si; long long n; unsigned long long seed; long long env_id_offset;
+  SimK<T> c; Quad<T>* sr; int4* si; long long n; unsigned long long seed; long long env_id_offset;
   T hover, vz_integ, r_lo, r_hi, t_lo, t_hi;
 };
 template <typename T> __global__ void k_init(InitArgs<T> a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  const DevC<T>& s = a.c;
+  const SimK<T>& s = a.c;
   uint32_t r[4];
   philox4x32(0u, 0u, (uint32_t)(a.env_id_offset + i), STREAM_INIT, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
   Env<T> e;
@@ -109,7 +114,8 @@ template <typename T> __global__ void k_init(InitArgs<T> a) {
 }
 
 template <typename T> struct StepArgs {
-  DevC<T> c;
+  SimK<T> c;
+  const MdpK<T>* mdp;
   Quad<T>* sr; int4* si;
   const double* qa; const double* qb;
   unsigned long long* accum;  // [2][DQL_N_CELLS]: target sums (fixed point), visits
@@ -128,7 +134,10 @@ DQL_DEV long long wave_sum(long long v) {
   return v;
 }
 
-template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOCK) void k_step(StepArgs<T> a) {
+#ifndef DQL_WAVES_PER_EU
+#define DQL_WAVES_PER_EU 1
+#endif
+template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
   __shared__ unsigned long long sT[DQL_N_CELLS];
   __shared__ unsigned int sM[DQL_N_CELLS];
   __shared__ unsigned long long sStat[4];
@@ -150,8 +159,8 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
     load_env(e, a.sr, a.si, a.n, i, a.c);
     const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
     StepOut o;
-    if (LDS_TAB) o = agent_period(a.c, e, (const double*)sQ, (const double*)(sQ + DQL_N_CELLS), a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
-    else o = agent_period(a.c, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
+    if (LDS_TAB) o = agent_period(a.c, a.mdp, e, (const double*)sQ, (const double*)(sQ + DQL_N_CELLS), a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
+    else o = agent_period(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
     store_env(e, a.sr, a.si, a.n, i, a.c);
     if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
     dec = o.decision; don = o.done; rfx = o.reward_fx;
@@ -247,12 +256,12 @@ __global__ void k_transfer(double* qa, double* qb, int k, int src, double ratio)
 }
 
 // ---- stateless operators ----
-template <typename T> __global__ void k_discretise(DevC<T> c, const double* p, const double* v, const double* acc, const double* ang, long long n, int* out) {
+template <typename T> __global__ void k_discretise(MdpK<T> c, const double* p, const double* v, const double* acc, const double* ang, long long n, int* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = discretise(c, (T)p[i], (T)v[i], (T)acc[i], (T)ang[i]);
 }
 template <typename T>
-__global__ void k_mdp_transition(DevC<T> c, long long n, const uint8_t* action, const double* obs, double* ms, const int* prev_idx, int* idx_out,
+__global__ void k_mdp_transition(MdpK<T> c, long long n, const uint8_t* action, const double* obs, double* ms, const int* prev_idx, int* idx_out,
                                  double* reward_out, uint8_t* done_out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -307,6 +316,7 @@ struct dql_ctx {
   double* alpha_tab = nullptr; int n_tab = 0;
   Sched* sched = nullptr; StatsDev* stats = nullptr;
   uint8_t* d_actions = nullptr;
+  void* mdpk = nullptr;  // MdpK<T> in device memory
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per-launch event pairs while the kernel timer is armed
@@ -330,9 +340,15 @@ static int check_config(const dql_config* c) {
   return DQL_OK;
 }
 
+static int upload_mdpk(dql_ctx* x) {
+  if (x->dtype == DQL_F32) { const MdpK<float> m = make_mdpk<float>(x->cfg); HIP_TRY(hipMemcpyAsync(x->mdpk, &m, sizeof(m), hipMemcpyHostToDevice, x->stream)); }
+  else { const MdpK<double> m = make_mdpk<double>(x->cfg); HIP_TRY(hipMemcpyAsync(x->mdpk, &m, sizeof(m), hipMemcpyHostToDevice, x->stream)); }
+  HIP_TRY(hipStreamSynchronize(x->stream));  // the source is a stack temporary
+  return DQL_OK;
+}
 template <typename T> static int launch_init(dql_ctx* x) {
   InitArgs<T> a;
-  a.c = make_devc<T>(x->cfg);
+  a.c = make_simk<T>(x->cfg);
   a.sr = (Quad<T>*)x->sr; a.si = x->si; a.n = x->n; a.seed = x->seed; a.env_id_offset = x->env_id_offset;
   const dql_config& c = x->cfg;
   a.hover = std::sqrt((T)(c.mass * c.gravity / (4.0 * c.k_f)));
@@ -355,7 +371,8 @@ static int host_sched_init(dql_ctx* x) {
 
 template <typename T, int BLOCK, bool LDS_TAB> static void launch_step_t(dql_ctx* x, int mode, double eps) {
   StepArgs<T> a;
-  a.c = make_devc<T>(x->cfg);
+  a.c = make_simk<T>(x->cfg);
+  a.mdp = (const MdpK<T>*)x->mdpk;
   a.sr = (Quad<T>*)x->sr; a.si = x->si; a.qa = x->qa; a.qb = x->qb; a.accum = (unsigned long long*)x->accum; a.stats = x->stats;
   a.sched = x->sched; a.actions = x->d_actions; a.n = x->n; a.env_id_offset = x->env_id_offset; a.seed = x->seed; a.eps = eps; a.mode = mode;
   hipLaunchKernelGGL((k_step<T, BLOCK, LDS_TAB>), dim3((unsigned)((x->n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, x->stream, a);
@@ -492,7 +509,7 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
   ALLOC(x->qa_base, DQL_N_CELLS * sizeof(double)); ALLOC(x->count_base, DQL_N_CELLS * sizeof(double));
   ALLOC(x->accum, 2 * DQL_N_CELLS * sizeof(long long)); ALLOC(x->window_own, 2 * DQL_N_CELLS * sizeof(long long)); x->window = x->window_own;
-  ALLOC(x->sched, sizeof(Sched)); ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n);
+  ALLOC(x->sched, sizeof(Sched)); ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n); ALLOC(x->mdpk, sizeof(MdpK<double>));
 #undef ALLOC
   HIP_TRY(hipMemsetAsync(x->sr, 0, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size, x->stream));
   HIP_TRY(hipMemsetAsync(x->qa, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->qb, 0, DQL_N_CELLS * sizeof(double), x->stream));
@@ -500,6 +517,8 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   HIP_TRY(hipMemsetAsync(x->qa_base, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->count_base, 0, DQL_N_CELLS * sizeof(double), x->stream));
   HIP_TRY(hipMemsetAsync(x->accum, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream)); HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
   HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream)); HIP_TRY(hipMemsetAsync(x->d_actions, 2, (size_t)x->n, x->stream));
+  rc = upload_mdpk(x);
+  if (rc) { dql_destroy(x); return rc; }
   rc = (x->dtype == DQL_F32) ? launch_init<float>(x) : launch_init<double>(x);
   if (rc) { dql_destroy(x); return rc; }
   rc = host_sched_init(x);
@@ -517,7 +536,7 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window_own, x->alpha_tab, x->sched, x->stats, x->d_actions};
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window_own, x->alpha_tab, x->sched, x->stats, x->d_actions, x->mdpk};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -553,6 +572,9 @@ int dql_set_curriculum(dql_ctx* x, int32_t k) {
   CHECK_CTX(x);
   if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
   x->cfg.working_curriculum_step = k;
+  HIP_TRY(hipSetDevice(x->device));
+  int rc = upload_mdpk(x);
+  if (rc) return rc;
   return dql_reset(x, nullptr);
 }
 
@@ -856,8 +878,8 @@ int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const
   UP(p, rel_p, B); UP(v, rel_v, B); UP(a, rel_a, B); UP(t, angle, B);
   if (o.alloc((size_t)n * sizeof(int))) return fail(DQL_ENOMEM, "hipMalloc failed");
   const unsigned grid = (unsigned)((n + 255) / 256);
-  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_discretise<float>, dim3(grid), dim3(256), 0, 0, make_devc<float>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
-  else hipLaunchKernelGGL(k_discretise<double>, dim3(grid), dim3(256), 0, 0, make_devc<double>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_discretise<float>, dim3(grid), dim3(256), 0, 0, make_mdpk<float>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
+  else hipLaunchKernelGGL(k_discretise<double>, dim3(grid), dim3(256), 0, 0, make_mdpk<double>(*cfg), (const double*)p.p, (const double*)v.p, (const double*)a.p, (const double*)t.p, (long long)n, (int*)o.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(idx_out, o.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   return DQL_OK;
@@ -874,8 +896,8 @@ int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, const uint8
   UP(a, action, (size_t)n); UP(o, obs, (size_t)n * 7 * sizeof(double)); UP(ms, mdp_state, (size_t)n * 8 * sizeof(double)); UP(pi, prev_idx, (size_t)n * sizeof(int));
   if (io.alloc((size_t)n * sizeof(int)) || ro.alloc((size_t)n * sizeof(double)) || dn.alloc((size_t)n)) return fail(DQL_ENOMEM, "hipMalloc failed");
   const unsigned grid = (unsigned)((n + 255) / 256);
-  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_mdp_transition<float>, dim3(grid), dim3(256), 0, 0, make_devc<float>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
-  else hipLaunchKernelGGL(k_mdp_transition<double>, dim3(grid), dim3(256), 0, 0, make_devc<double>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_mdp_transition<float>, dim3(grid), dim3(256), 0, 0, make_mdpk<float>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  else hipLaunchKernelGGL(k_mdp_transition<double>, dim3(grid), dim3(256), 0, 0, make_mdpk<double>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(mdp_state, ms.p, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(idx_out, io.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));

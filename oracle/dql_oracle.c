@@ -525,7 +525,8 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   const REAL dyq = FMA(qw, w[1], FMA(qz, w[0], -(qx * w[2])));
   const REAL dzq = FMA(qw, w[2], FMA(qx, w[1], -(qy * w[0])));
   const REAL nw = FMA(hdt, dw, qw), nx = FMA(hdt, dxq, qx), ny = FMA(hdt, dyq, qy), nz = FMA(hdt, dzq, qz);
-  const REAL inv = R_(1.0) / SQRT(FMA(nw, nw, FMA(nx, nx, FMA(ny, ny, nz * nz))));
+  /* renormalise with one Newton step of 1/sqrt(|q|^2) about 1: |q|^2 - 1 = O((dt |w|)^2), so the residual is O(dt^4) */
+  const REAL inv = FMA(R_(-0.5), FMA(nw, nw, FMA(nx, nx, FMA(ny, ny, nz * nz))), R_(1.5));
   e->q[0] = nw * inv; e->q[1] = nx * inv; e->q[2] = ny * inv; e->q[3] = nz * inv;
 }
 

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3 counter passes: N envs, S train steps."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
+from dql_multirotor_landing_amd.engine import Engine
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+e = Engine(DqlConfig(dtype=F32), n, seed=42)
+e.set_option("block", block)
+e.train_steps(steps, 1.0)
+e.sync()
+print(e.stats())
