@@ -171,7 +171,7 @@ template <typename T> struct MdpK {
   T w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   T lim_p[5], lim_v[5], lim_a[5], angles[7];
   double gamma;
-  int working;
+  int working, goal_logic;
   uint32_t quirks;
 };
 // SimK: constants of the physics tick loop (kernel argument by value).
@@ -269,7 +269,7 @@ DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int cod
   else if (abs_p_z < m.min_alt) code = DQL_TERMINAL_MINIMUM_ALTITUDE;
   else if (abs_p_z > m.p_max) code = DQL_TERMINAL_FLYZONE_Z;
   else if ((T)step_count >= m.timeout_steps) code = DQL_TERMINAL_TIMEOUT;
-  else if (prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
+  else if (m.goal_logic && prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
     if (idx_level(prev_idx) == m.working && idx_level(cur_idx) == m.working) {
       cur_check += 1;
       code = ((T)cur_check >= m.f_ag) ? DQL_TERMINAL_SUCCESS : DQL_NON_TERMINAL_SUCCESS;

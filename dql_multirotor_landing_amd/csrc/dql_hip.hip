@@ -51,7 +51,7 @@ template <typename T> static MdpK<T> make_mdpk(const dql_config& c) {
   const double step = (c.theta_max - (-c.theta_max)) / 6.0;  // np.linspace(-theta_max, theta_max, 7), pkg/mdp.py:145
   for (int i = 0; i < 6; ++i) d.angles[i] = (T)((double)i * step + (-c.theta_max));
   d.angles[6] = (T)c.theta_max;
-  d.gamma = c.gamma; d.working = c.working_curriculum_step; d.quirks = c.quirks;
+  d.gamma = c.gamma; d.working = c.working_curriculum_step; d.goal_logic = c.goal_logic; d.quirks = c.quirks;
   return d;
 }
 template <typename T> static SimK<T> make_simk(const dql_config& c) {
@@ -261,20 +261,24 @@ template <typename T> __global__ void k_discretise(MdpK<T> c, const double* p, c
   if (i < n) out[i] = discretise(c, (T)p[i], (T)v[i], (T)acc[i], (T)ang[i]);
 }
 template <typename T>
-__global__ void k_mdp_transition(MdpK<T> c, long long n, const uint8_t* action, const double* obs, double* ms, const int* prev_idx, int* idx_out,
-                                 double* reward_out, uint8_t* done_out) {
+__global__ void k_mdp_transition(MdpK<T> c, long long n, uint32_t stages, const uint8_t* action, const double* obs, double* ms, const int* prev_idx,
+                                 int* idx_io, double* reward_out, uint8_t* done_out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   T sp = (T)ms[0 * n + i], shp_p = (T)ms[1 * n + i], shp_v = (T)ms[2 * n + i], shp_a = (T)ms[3 * n + i], cum = (T)ms[4 * n + i];
   int step_count = (int)ms[5 * n + i], cur_check = (int)ms[6 * n + i], code = (int)ms[7 * n + i];
-  sp = continuous_action(c, sp, (int)action[i]);
   const T px = (T)obs[0 * n + i], py = (T)obs[1 * n + i], vx = (T)obs[2 * n + i], ax = (T)obs[3 * n + i], pitch = (T)obs[4 * n + i], z = (T)obs[5 * n + i];
   const bool contact = obs[6 * n + i] != 0.0;
-  const int idx = discretise(c, px, vx, ax, pitch);
-  idx_out[i] = idx;
-  code = mdp_check(c, step_count, cur_check, code, prev_idx[i], idx < 0 ? 0 : idx, contact, px, py, z);
-  const T rew = mdp_reward(c, shp_p, shp_v, shp_a, cum, code, idx < 0 ? 0 : idx, px, vx, sp);
-  reward_out[i] = (double)rew; done_out[i] = code <= DQL_TERMINAL_TIMEOUT;
+  if (stages & DQL_MDP_ACTION) sp = continuous_action(c, sp, (int)action[i]);
+  int idx = idx_io[i];
+  if (stages & DQL_MDP_DISCRETISE) { idx = discretise(c, px, vx, ax, pitch); idx_io[i] = idx; }
+  const int sidx = idx < 0 ? 0 : idx;
+  if (stages & DQL_MDP_CHECK) {
+    // SimulationMdp.check has no goal logic: feeding prev = -1 disables that branch (pkg/mdp.py:784-845)
+    code = mdp_check(c, step_count, cur_check, code, (stages & DQL_MDP_SIMULATION) ? -1 : prev_idx[i], sidx, contact, px, py, z);
+    done_out[i] = code <= DQL_TERMINAL_TIMEOUT;
+  }
+  if (stages & DQL_MDP_REWARD) reward_out[i] = (double)mdp_reward(c, shp_p, shp_v, shp_a, cum, code, sidx, px, vx, sp);
   ms[0 * n + i] = sp; ms[1 * n + i] = shp_p; ms[2 * n + i] = shp_v; ms[3 * n + i] = shp_a; ms[4 * n + i] = cum;
   ms[5 * n + i] = step_count; ms[6 * n + i] = cur_check; ms[7 * n + i] = code;
 }
@@ -481,7 +485,7 @@ int dql_config_default(dql_config* c) {
   const double pv[6] = {5.0, 10.0, 0.0, 0.0, 10.0, 10.0}, py[6] = {8.0, 1.0, 0.0, -3.141592, 3.141592, 5.0};
   for (int i = 0; i < 6; ++i) { c->pid_vz[i] = pv[i]; c->pid_yaw[i] = py[i]; }
   c->bw_c = 1.0; c->mp_r_x = 2.0; c->mp_t_x = 1.6; c->mp_dt = 0.01; c->mp_top_z = 0.455; c->mp_half_x = 0.55; c->mp_half_y = 0.55; c->drone_bottom = 0.06;
-  c->z_init = 4.0; c->init_sigma = 4.5 / 3; c->init_uniform = 0; c->per_env_platform = 0;
+  c->z_init = 4.0; c->init_sigma = 4.5 / 3; c->init_uniform = 0; c->per_env_platform = 0; c->goal_logic = 1; c->reserved0 = 0;
   c->mp_r_lo = 1.0; c->mp_r_hi = 3.0; c->mp_t_lo = 0.8; c->mp_t_hi = 1.6;
   c->noise_pos_sd = 0.0; c->noise_vel_sd = 0.0; c->kalman_q = 1e-4;
   return DQL_OK;
@@ -885,24 +889,40 @@ int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const
   return DQL_OK;
 }
 
-int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, const uint8_t* action, const double* obs, double* mdp_state, const int32_t* prev_idx,
-                       int32_t* idx_out, double* reward_out, uint8_t* done_out) {
+int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t stages, const uint8_t* action, const double* obs, double* mdp_state,
+                       const int32_t* prev_idx, int32_t* idx_io, double* reward_out, uint8_t* done_out) {
   int rc = check_config(cfg); if (rc) return rc;
-  if (n < 0 || (n > 0 && (!action || !obs || !mdp_state || !prev_idx || !idx_out || !reward_out || !done_out))) return fail(DQL_EINVAL, "null array");
+  if (n < 0 || (n > 0 && (!action || !obs || !mdp_state || !prev_idx || !idx_io || !reward_out || !done_out))) return fail(DQL_EINVAL, "null array");
   if (n == 0) return DQL_OK;
+  if ((stages & DQL_MDP_ALL) == 0) return fail(DQL_EINVAL, "no stage selected");
   for (int64_t i = 0; i < n; ++i) if (action[i] > 2) return fail(DQL_EINVAL, "action must be 0, 1 or 2");
+  if ((stages & (DQL_MDP_CHECK | DQL_MDP_REWARD)) && !(stages & DQL_MDP_DISCRETISE))
+    for (int64_t i = 0; i < n; ++i) if (idx_io[i] < 0 || idx_io[i] >= DQL_N_STATES) return fail(DQL_ESTATE, "Cannot check an empty state: call discrete_state first");
   OP_PROLOGUE(device)
   DevBuf a, o, ms, pi, io, ro, dn;
   UP(a, action, (size_t)n); UP(o, obs, (size_t)n * 7 * sizeof(double)); UP(ms, mdp_state, (size_t)n * 8 * sizeof(double)); UP(pi, prev_idx, (size_t)n * sizeof(int));
-  if (io.alloc((size_t)n * sizeof(int)) || ro.alloc((size_t)n * sizeof(double)) || dn.alloc((size_t)n)) return fail(DQL_ENOMEM, "hipMalloc failed");
+  UP(io, idx_io, (size_t)n * sizeof(int)); UP(ro, reward_out, (size_t)n * sizeof(double)); UP(dn, done_out, (size_t)n);
   const unsigned grid = (unsigned)((n + 255) / 256);
-  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_mdp_transition<float>, dim3(grid), dim3(256), 0, 0, make_mdpk<float>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
-  else hipLaunchKernelGGL(k_mdp_transition<double>, dim3(grid), dim3(256), 0, 0, make_mdpk<double>(*cfg), (long long)n, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_mdp_transition<float>, dim3(grid), dim3(256), 0, 0, make_mdpk<float>(*cfg), (long long)n, stages, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
+  else hipLaunchKernelGGL(k_mdp_transition<double>, dim3(grid), dim3(256), 0, 0, make_mdpk<double>(*cfg), (long long)n, stages, (const uint8_t*)a.p, (const double*)o.p, (double*)ms.p, (const int*)pi.p, (int*)io.p, (double*)ro.p, (uint8_t*)dn.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(mdp_state, ms.p, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(idx_out, io.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(idx_io, io.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(reward_out, ro.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(done_out, dn.p, (size_t)n, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_agent_transfer(int device, double* qa, double* qb, int32_t k, double ratio) {
+  if (!qa || !qb) return fail(DQL_EINVAL, "null array");
+  if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
+  OP_PROLOGUE(device)
+  DevBuf a, b;
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  UP(a, qa, B); UP(b, qb, B);
+  hipLaunchKernelGGL(k_transfer, dim3((DQL_CELLS_PER_LEVEL + 255) / 256), dim3(256), 0, 0, (double*)a.p, (double*)b.p, (int)k, (int)((k - 1 + DQL_MAX_LEVELS) % DQL_MAX_LEVELS), ratio);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(qa, a.p, B, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(qb, b.p, B, hipMemcpyDeviceToHost));
   return DQL_OK;
 }
 

@@ -1,0 +1,117 @@
+"""Drop-in mirror of the reference's `double_q_learning.py` (pkg/double_q_learning.py:32-146): same class,
+attributes, methods, file names and `.npy` layout.  The table arithmetic (argmax, TD update, transfer scaling) runs
+on the device through the C ABI (`dql_agent_predict`, `dql_agent_update`, `dql_agent_transfer`); the host draws the
+reference's `np.random` numbers so that a seeded run consumes the global MT19937 stream exactly as the reference
+does (B1, B4)."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Tuple, Union
+
+import numpy as np
+
+from . import ops
+from .config import MAX_LEVELS, Q_REFERENCE, TABLE_SHAPE
+from .mdp import pack_state
+
+State = Tuple[int, int, int, int, int]
+StateAction = Tuple[int, int, int, int, int, int]
+
+ASSETS_PATH = Path(__file__).resolve().parent.parent / "assets"  # the reference resolves this through rospkg (pkg/__init__.py:5-7)
+
+
+class DoubleQLearningAgent:
+    """Agent that learns and makes decisions (two (S,3,3,3,7,3) float64 tables + visit counter)."""
+
+    def __init__(self, curriculum_steps: int = 5, device: int = 0) -> None:
+        if not 1 <= curriculum_steps <= MAX_LEVELS:
+            raise ValueError(f"curriculum_steps must be in 1..{MAX_LEVELS}")
+        self.curriculum_steps = curriculum_steps
+        shape = (curriculum_steps,) + TABLE_SHAPE[1:]
+        self.Q_table_a = np.zeros(shape)
+        self.Q_table_b = np.zeros(shape)
+        self.state_action_counter = np.zeros(shape)
+        self._device = device
+
+    # ---- persistence: pkg/double_q_learning.py:42-75 ----
+    def save(self, save_path: Path):
+        save_path = Path(save_path)
+        for name, arr in (("Q_table_a.npy", self.Q_table_a), ("Q_table_b.npy", self.Q_table_b), ("state_action_count.npy", self.state_action_counter)):
+            with open(save_path / name, "wb") as f:
+                np.save(f, np.ascontiguousarray(arr, dtype=np.float64))
+
+    @staticmethod
+    def load(save_path: Path = ASSETS_PATH):
+        save_path = Path(save_path)
+        with open(save_path / "Q_table_a.npy", "rb") as f:
+            qa = np.load(f, allow_pickle=False)
+        with open(save_path / "Q_table_b.npy", "rb") as f:
+            qb = np.load(f, allow_pickle=False)
+        with open(save_path / "state_action_count.npy", "rb") as f:
+            sac = np.load(f, allow_pickle=False)
+        if qa.shape != qb.shape != sac.shape:  # chained comparison kept as in the reference (:66, B12)
+            raise ValueError(f"The shapes of Q table a {qa.shape}, Q table b {qb.shape}and State action count {sac.shape} cannot be different")
+        agent = DoubleQLearningAgent(len(qa))
+        agent.Q_table_a, agent.Q_table_b, agent.state_action_counter = qa, qb, sac
+        return agent
+
+    # ---- device round trips: tables padded to the 5-level device layout ----
+    def _padded(self):
+        def pad(t):
+            out = np.zeros(TABLE_SHAPE, dtype=np.float64)
+            out[: self.curriculum_steps] = t
+            return out.reshape(-1)
+        return pad(self.Q_table_a), pad(self.Q_table_b), pad(self.state_action_counter)
+
+    def _unpad(self, qa, qb, cnt):
+        n = self.curriculum_steps
+        self.Q_table_a = qa.reshape(TABLE_SHAPE)[:n].copy()
+        self.Q_table_b = qb.reshape(TABLE_SHAPE)[:n].copy()
+        self.state_action_counter = cnt.reshape(TABLE_SHAPE)[:n].copy()
+
+    def _check_state(self, state, n):
+        if len(state) != n:
+            raise IndexError(f"expected an index tuple of length {n}")
+        dims = (self.curriculum_steps, 3, 3, 3, 7, 3)[:n]
+        for v, d in zip(state, dims):
+            if not -d <= int(v) < d:
+                raise IndexError(f"index {v} is out of bounds for axis with size {d}")
+        return tuple(int(v) % d for v, d in zip(state, dims))
+
+    # ---- pkg/double_q_learning.py:77-89 ----
+    def transfer_learning(self, current_curriculum_step: int, transfer_learning_ratio: float):
+        k = int(current_curriculum_step)
+        if not 0 <= k < self.curriculum_steps:
+            raise IndexError(f"index {k} is out of bounds for axis 0 with size {self.curriculum_steps}")
+        if self.curriculum_steps != MAX_LEVELS and k == 0:
+            # the k = 0 wrap reads the LAST level of the table (B6); with a shorter table do the wrap on the padded copy
+            qa, qb, cnt = self._padded()
+            src = self.curriculum_steps - 1
+            qa.reshape(TABLE_SHAPE)[MAX_LEVELS - 1] = qa.reshape(TABLE_SHAPE)[src]
+            qb.reshape(TABLE_SHAPE)[MAX_LEVELS - 1] = qb.reshape(TABLE_SHAPE)[src]
+        else:
+            qa, qb, cnt = self._padded()
+        ops.agent_transfer(qa, qb, k, transfer_learning_ratio, device=self._device)
+        self._unpad(qa, qb, cnt)
+
+    # ---- pkg/double_q_learning.py:91-108, 126-146 ----
+    def update(self, current_state_action: StateAction, next_state: State, alpha: float, gamma: float, reward):
+        sa = self._check_state(current_state_action, 6)
+        ns = self._check_state(next_state, 5)
+        np.random.uniform(0, 1)  # drawn and ignored: both arms select Q_table_a (B1)
+        qa, qb, cnt = self._padded()
+        ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
+                         quirks=Q_REFERENCE, device=self._device)
+        self._unpad(qa, qb, cnt)
+
+    # ---- pkg/double_q_learning.py:110-124 ----
+    def guess(self, state: State, exploration_rate: float):
+        explore = np.random.uniform(0, 1) < exploration_rate
+        return int(np.where(explore, np.random.randint(3), self.predict(state)))  # randint always drawn (B4)
+
+    def predict(self, state: State):
+        s = self._check_state(state, 5)
+        qa, qb, _ = self._padded()
+        return int(ops.agent_predict(qa, qb, [pack_state(s)], device=self._device)[0])
+
+    get_action = guess  # name used by BASELINE.json's north_star

@@ -29,16 +29,30 @@ def discretise(cfg: DqlConfig, rel_p, rel_v, rel_a, angle, device: int = 0) -> n
     return out
 
 
-def mdp_transition(cfg: DqlConfig, action, obs, mdp_state, prev_idx, device: int = 0):
+MDP_ACTION, MDP_DISCRETISE, MDP_CHECK, MDP_REWARD, MDP_SIMULATION, MDP_ALL = 1, 2, 4, 8, 16, 15
+
+
+def mdp_transition(cfg: DqlConfig, action, obs, mdp_state, prev_idx, idx=None, stages: int = MDP_ALL, device: int = 0):
+    """Selected TrainingMdp / SimulationMdp methods (see DQL_MDP_* in include/dql.h) for n independent MDPs.
+    Returns (mdp_state, idx, reward, done); arrays not touched by the selected stages come back unchanged / zero."""
     n = len(action)
     action = np.ascontiguousarray(action, dtype=np.uint8)
     obs = _f64(obs); ms = _f64(mdp_state).copy(); prev_idx = np.ascontiguousarray(prev_idx, dtype=np.int32)
     if obs.shape != (7, n) or ms.shape != (8, n) or prev_idx.shape != (n,):
         raise ValueError("obs must be [7][n], mdp_state [8][n], prev_idx [n]")
-    idx = np.zeros(n, dtype=np.int32); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
+    idx = np.full(n, -1, dtype=np.int32) if idx is None else np.ascontiguousarray(idx, dtype=np.int32).copy()
+    rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
     c = cfg.to_c()
-    _lib.check(_lib.load().dql_mdp_transition(C.byref(c), device, n, _p(action), _p(obs), _p(ms), _p(prev_idx), _p(idx), _p(rew), _p(done)))
+    _lib.check(_lib.load().dql_mdp_transition(C.byref(c), device, n, stages, _p(action), _p(obs), _p(ms), _p(prev_idx), _p(idx), _p(rew), _p(done)))
     return ms, idx, rew, done
+
+
+def agent_transfer(qa, qb, k: int, ratio: float, device: int = 0):
+    """In-place DoubleQLearningAgent.transfer_learning on contiguous float64 tables of 2835 cells."""
+    for t in (qa, qb):
+        if t.dtype != np.float64 or not t.flags.c_contiguous or t.size != 2835:
+            raise ValueError("tables must be contiguous float64 arrays of 2835 cells")
+    _lib.check(_lib.load().dql_agent_transfer(device, _p(qa), _p(qb), int(k), float(ratio)))
 
 
 def agent_predict(qa, qb, idx, device: int = 0) -> np.ndarray:

@@ -107,6 +107,8 @@ typedef struct dql_config {
   double z_init, init_sigma;    /* pkg/trainer.py:41 (4.0), p_max/3 (landing_simulation_env.py:189) */
   int32_t init_uniform;         /* 0: N(0,sigma) at level 0 else U (TrainingLandingEnv.reset); 1: always U (Simulation env) */
   int32_t per_env_platform;     /* 1: r_x, t_x drawn per env from the ranges below (BASELINE config 5) */
+  int32_t goal_logic;           /* 1: TrainingMdp.check goal / success branch (pkg/mdp.py:402-425); 0: SimulationMdp.check (:784-845) */
+  int32_t reserved0;
   double mp_r_lo, mp_r_hi, mp_t_lo, mp_t_hi;
   double noise_pos_sd, noise_vel_sd, kalman_q; /* scripts/manager_node.py:83-98 */
 } dql_config;
@@ -205,18 +207,26 @@ int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 /* TrainingMdp.discrete_state (pkg/mdp.py:257-333): 4 x double[n] -> packed idx int32[n]; -1 where the reference raises */
 int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const double* rel_v, const double* rel_a,
                    const double* angle, int64_t n, int32_t* idx_out);
-/* TrainingMdp continuous_action + discrete_state + check + reward for n independent MDPs, one transition each
- * (pkg/mdp.py:335-560).  mdp_state: double[8][n] in/out = pitch_sp, shaping_p, shaping_v, shaping_a, cumulative,
- * step_count, curriculum_check, check_code; prev_idx int32[n] in (-1 = none), idx out */
-int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, const uint8_t* action, const double* obs /*[7][n]:
-                       rel_p_x rel_p_y rel_v_x rel_a_x pitch abs_p_z contact*/, double* mdp_state, const int32_t* prev_idx,
-                       int32_t* idx_out, double* reward_out, uint8_t* done_out);
+/* TrainingMdp / SimulationMdp methods for n independent MDPs (pkg/mdp.py:257-560, 625-877).  `stages` selects which
+ * of the reference's methods run in this call, in the reference's call order:
+ *   DQL_MDP_ACTION (continuous_action) | DQL_MDP_DISCRETISE (discrete_state) | DQL_MDP_CHECK (check) | DQL_MDP_REWARD (reward)
+ *   DQL_MDP_SIMULATION: SimulationMdp.check flavour (no goal / success logic, pkg/mdp.py:784-845)
+ * mdp_state: double[8][n] in/out = angle set-point, shaping_p, shaping_v, shaping_a, cumulative, step_count,
+ * curriculum_check, check_code; prev_idx int32[n] in (-1 = none); idx_io int32[n]: current packed state, written by
+ * DISCRETISE and read by CHECK / REWARD; obs double[7][n] = rel_p (axis), rel_p (other axis), rel_v, rel_a, angle,
+ * abs_p_z, contact */
+enum { DQL_MDP_ACTION = 1, DQL_MDP_DISCRETISE = 2, DQL_MDP_CHECK = 4, DQL_MDP_REWARD = 8, DQL_MDP_SIMULATION = 16, DQL_MDP_ALL = 15 };
+int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t stages, const uint8_t* action, const double* obs,
+                       double* mdp_state, const int32_t* prev_idx, int32_t* idx_io, double* reward_out, uint8_t* done_out);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:
  * sa int32[n] = cell index (idx*3+action), ns int32[n] = packed next state; tables updated in place */
 int dql_agent_update(int device, double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns,
                      const double* alpha, double gamma, const double* reward, int64_t n, uint32_t quirks);
+
+/* DoubleQLearningAgent.transfer_learning (pkg/double_q_learning.py:77-89) on host tables: Q[k] = Q[k-1] * ratio (k = 0 wraps, B6) */
+int dql_agent_transfer(int device, double* qa, double* qb, int32_t k, double ratio);
 
 #ifdef __cplusplus
 }

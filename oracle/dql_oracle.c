@@ -245,7 +245,7 @@ typedef struct {
   REAL p_max, v_max, a_max, theta_max, delta_theta, beta, sigma_a, min_alt;
   REAL w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   REAL lim_p[5], lim_v[5], lim_a[5], angles[7];
-  int working;
+  int working, goal_logic;
   uint32_t quirks;
 } mdpc_t;
 
@@ -262,7 +262,7 @@ static void mdpc_init(mdpc_t* m, const dql_config* c) {
   const double step = (c->theta_max - (-c->theta_max)) / 6.0;
   for (int i = 0; i < 6; ++i) m->angles[i] = (REAL)((double)i * step + (-c->theta_max));
   m->angles[6] = (REAL)c->theta_max;
-  m->working = c->working_curriculum_step;
+  m->working = c->working_curriculum_step; m->goal_logic = c->goal_logic;
   m->quirks = c->quirks;
 }
 static inline REAL clip(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -324,7 +324,7 @@ static int mdp_check(const mdpc_t* m, int* step_count, int* cur_check, int code,
   else if (abs_p_z < m->min_alt) code = DQL_TERMINAL_MINIMUM_ALTITUDE;
   else if (abs_p_z > m->p_max) code = DQL_TERMINAL_FLYZONE_Z;
   else if ((REAL)*step_count >= m->timeout_steps) code = DQL_TERMINAL_TIMEOUT;
-  else if (prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
+  else if (m->goal_logic && prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
     if (idx_level(prev_idx) == m->working && idx_level(cur_idx) == m->working) {
       *cur_check += 1;
       code = ((REAL)*cur_check >= m->f_ag) ? DQL_TERMINAL_SUCCESS : DQL_NON_TERMINAL_SUCCESS;

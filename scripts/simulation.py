@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's scripts/simulation.py (load tables, run greedy landing episodes): evaluates a
+pair of Q tables in the vectorised simulator and reports how the episodes end.
+
+    python scripts/simulation.py [--tables DIR] [--envs 4096] [--episodes-per-env 1] [--level 4]
+Default tables: tests/golden/assets (a data copy of the reference's stage-4 policy).
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def evaluate(tables_dir, n_envs=4096, level=4, max_steps=600, seed=123, dtype=None, flavour="simulation", device=0, **cfg_kw):
+    """Greedy roll-outs; returns the terminal histogram of the FIRST episode of every env."""
+    import numpy as np
+    from dql_multirotor_landing_amd.config import CHECK_NAMES, F32, simulation_config, training_config
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    from dql_multirotor_landing_amd.engine import Engine
+    agent = DoubleQLearningAgent.load(Path(tables_dir))
+    dtype = F32 if dtype is None else dtype
+    if flavour == "simulation":
+        cfg = simulation_config(working_curriculum_step=level, dtype=dtype, **cfg_kw)
+    else:
+        cfg = training_config(level, dtype=dtype, **cfg_kw)
+    eng = Engine(cfg, n_envs, seed=seed, device=device)
+    eng.set_tables(*agent._padded())
+    first_code = np.full(n_envs, -1, dtype=np.int64)
+    eng.eval_steps(1)  # reset period
+    for _ in range(max_steps):
+        eng.eval_steps(1)
+        d, c = eng.dones()
+        new = (d != 0) & (first_code < 0)
+        first_code[new] = c[new]
+        if (first_code >= 0).all():
+            break
+    hist = {CHECK_NAMES[k]: int((first_code == k).sum()) for k in range(len(CHECK_NAMES))}
+    hist["unfinished"] = int((first_code < 0).sum())
+    eng.close()
+    return hist
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tables", default=str(Path(__file__).resolve().parent.parent / "tests" / "golden" / "assets"))
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--level", type=int, default=4)
+    ap.add_argument("--flavour", default="simulation", choices=["simulation", "training"])
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build_hip()
+    h = evaluate(a.tables, a.envs, a.level, flavour=a.flavour)
+    n = a.envs
+    print(json.dumps({"tables": a.tables, "envs": n, "level": a.level, "flavour": a.flavour, "first_episode_outcomes": h,
+                      "touchdown_rate": h["TERMINAL_CONTACT"] / n, "goal_rate": h["TERMINAL_SUCCESS"] / n}, indent=1))

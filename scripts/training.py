@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's scripts/training.py (rospy.init_node; Trainer().curriculum_training()):
+curriculum training of the tabular Double-Q landing agent on one MI355X.
+
+    python scripts/training.py [--envs 4096] [--mode reference|paper] [--out DIR] [--max-steps-per-level N]
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--mode", default="reference", choices=["reference", "paper"])
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--max-steps-per-level", type=int, default=None)
+    ap.add_argument("--max-episodes", type=int, default=50000)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build_hip()
+    from dql_multirotor_landing_amd.config import F32, F64
+    from dql_multirotor_landing_amd.trainer import Trainer
+    tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk,
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose)
+    hist = tr.curriculum_training()
+    print(json.dumps({"history": hist, "save_path": str(tr._save_path)}, indent=1))

@@ -1,0 +1,127 @@
+"""The drop-in classes (reference names / signatures) on the GPU against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_mdp_replays_reference_trace(golden_dir):
+    from dql_multirotor_landing_amd.mdp import CheckResult, ContinuousObservation, Observation, TrainingMdp
+    codes = list(CheckResult)
+    for level in (0, 2, 4):
+        t = np.load(golden_dir / "g2_traces.npz")[f"trace_{level}"]
+        m = TrainingMdp(level, 22.92, 20, 4.5)
+        n = 0
+        for row in t[:500]:
+            obs = ContinuousObservation(Observation(rel_p_x=row[2], rel_p_y=row[3], rel_v_x=row[4], rel_a_x=row[5], contact=bool(row[8])),
+                                        pitch=row[6], abs_p_z=row[7])
+            if int(row[0]) == 0:
+                m.reset()
+                assert m.discrete_state(obs) == tuple(int(x) for x in row[9:14])
+                continue
+            a = m.continuous_action(int(row[1]))
+            assert a.pitch == row[17] and a.v_z == -0.1
+            assert m.discrete_state(obs) == tuple(int(x) for x in row[9:14])
+            info = m.check()
+            r = m.reward()
+            assert codes.index(m._check_result) == int(row[14])
+            assert r == row[15]
+            assert ("Termination condition" in info) == bool(row[16])
+            assert m._cumulative_reward == row[18] and m._step_count == int(row[19]) and m._curriculum_check == int(row[20])
+            if "Termination condition" in info:
+                assert info["Termination condition"] == m._check_result.value and info["Number of steps"] == m._step_count
+            n += 1
+        assert n > 300
+
+
+def test_simulation_mdp_replays_reference_trace(golden_dir):
+    from dql_multirotor_landing_amd.mdp import CheckResult, ContinuousObservation, Observation, SimulationMdp
+    codes = list(CheckResult)
+    t = np.load(golden_dir / "g2s_simulation.npz")["trace"]
+    m = SimulationMdp(4, 22.92, 20)
+    first = True
+    for row in t:
+        obs = ContinuousObservation(Observation(rel_p_x=row[3], rel_p_y=row[4], rel_v_x=row[5], rel_v_y=row[6], rel_a_x=row[7], rel_a_y=row[8],
+                                                contact=bool(row[12])), pitch=row[9], roll=row[10], abs_p_z=row[11])
+        if int(row[0]) == 0:
+            m.reset()
+        else:
+            a = m.continuous_action(int(row[1]), int(row[2]))
+            assert a.pitch == row[25] and a.roll == row[26] == 0.0
+        sx, sy = m.discrete_state(obs)
+        assert sx == tuple(int(x) for x in row[13:18]) and sy == tuple(int(x) for x in row[18:23])
+        if int(row[0]) == 1:
+            info = m.check()
+            assert codes.index(m._check_result) == int(row[23])
+            assert ("Termination condition" in info) == bool(row[24])
+
+
+def test_agent_guess_predict_update_match_reference_stream(golden_dir):
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    g = np.load(golden_dir / "g4_agent.npz")
+    agent = DoubleQLearningAgent.load(golden_dir / "assets")
+    for eps in (0.0, 0.5, 1.0):
+        np.random.seed(42)
+        acts = [agent.guess(tuple(int(x) for x in s), eps) for s in g["guess_states"][:200]]
+        np.testing.assert_array_equal(acts, g[f"guess_actions_eps{eps}"][:200])
+    np.random.seed(42)
+    for s in g["guess_states"]:
+        agent.get_action(tuple(int(x) for x in s), 0.5)
+    assert np.random.uniform(0, 1) == g["guess_rng_next_eps0.5"][0], "MT19937 stream position after 600 guesses (B4)"
+    # sequential updates incl. the ignored uniform draw (B1)
+    np.random.seed(42)
+    a = DoubleQLearningAgent(5)
+    n = 300
+    for i in range(n):
+        a.update(tuple(int(x) for x in g["upd_sa"][i]), tuple(int(x) for x in g["upd_ns"][i]), g["upd_alpha"][i], 0.99, g["upd_reward"][i])
+        assert a.Q_table_a[tuple(g["upd_sa"][i])] == g["upd_q_after"][i]
+    assert not a.Q_table_b.any() and a.state_action_counter.sum() == n
+    # transfer incl. the k = 0 wrap (B6)
+    t = DoubleQLearningAgent(5)
+    t.Q_table_a = g["tl_Qa_in"].copy(); t.Q_table_b = g["tl_Qb_in"].copy()
+    ratios = [1.0, 0.8172650252856599, 0.8211253690681617, 0.8257273369742982, 0.8311571820651724]
+    for k in range(5):
+        t.transfer_learning(k, ratios[k])
+        np.testing.assert_array_equal(t.Q_table_a, g[f"tl_Qa_after{k}"])
+        np.testing.assert_array_equal(t.Q_table_b, g[f"tl_Qb_after{k}"])
+
+
+def test_training_env_single_env_api():
+    from dql_multirotor_landing_amd.landing_simulation_env import TrainingLandingEnv, VecLandingEnv
+    env = TrainingLandingEnv(0, z_init=4.0, seed=5)
+    s = env.reset()
+    assert isinstance(s, tuple) and len(s) == 5 and s[0] == 0
+    done, steps, total = False, 0, 0.0
+    while not done and steps < 500:
+        s, r, done, info = env.step(steps % 3)
+        assert isinstance(r, float) and isinstance(done, bool) and "Current reward" in info
+        steps += 1; total += r
+    assert done and "Termination condition" in info and info["Number of steps"] == steps
+    with pytest.raises(ValueError):
+        env.step(0, 1)
+    env.close()
+    vec = VecLandingEnv(64, z_init=4.0, seed=5)
+    st = vec.reset()
+    assert st.shape == (64, 5)
+    st, rew, dones, info = vec.step(np.zeros(64, dtype=np.uint8))
+    assert rew.shape == (64,) and dones.dtype == bool and not info["was_reset"].any()
+    vec.close()
+
+
+def test_trainer_short_curriculum_run(tmp_path):
+    from dql_multirotor_landing_amd.trainer import Trainer
+    tr = Trainer(n_envs=1024, save_path=tmp_path / "run", chunk_steps=32, max_steps_per_level=256, checkpoint_every=2)
+    hist = tr.curriculum_training()
+    assert hist and hist[0]["level"] == 0 and hist[0]["agent_periods"] >= 256 or hist[0]["promoted"]
+    assert (tmp_path / "run" / "Q_table_a.npy").exists() and (tmp_path / "Q_table_a.npy").exists()
+    assert (tmp_path / "run" / "logs" / "scalars.csv").read_text().count("\n") > 2
+    assert tr._double_q_learning_agent.state_action_counter.sum() > 1000
+
+
+def test_greedy_evaluation_of_reference_tables(golden_dir):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import simulation
+    h = simulation.evaluate(golden_dir / "assets", n_envs=512, level=4, max_steps=520)
+    assert sum(h.values()) == 512 and h["unfinished"] == 0
