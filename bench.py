@@ -124,6 +124,13 @@ def main():
 
     if rank == 0:
         value = decisions / wall
+        traffic, traffic_note = None, "no committed PMC pass for this envs/block configuration"
+        tf = ROOT / "profiles" / "r1_traffic.json"
+        if tf.exists():
+            t = json.loads(tf.read_text())["configs"].get(str(args.envs))
+            if t:
+                traffic = t["hbm_bytes_per_env"] * dec_per_launch
+                traffic_note = "profiles/r1_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction) x env-steps per launch of this run"
         ach = ALGO_BYTES_PER_ENV_STEP * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -135,7 +142,7 @@ def main():
                        "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
