@@ -23,15 +23,16 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 ALGO_BYTES_PER_ENV_STEP = 320  # 40 four-byte words of persistent per-env state, read once + written once
+ALGO_BYTES_PER_ENV_STEP_2AXIS = 400  # 50 words in the 2-axis config
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
-def cpu_baseline(envs: int, steps: int, dtype: int):
+def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
     """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on ONE host core, bounded sample."""
     from dql_multirotor_landing_amd.config import DqlConfig
     from oracle.oracle import Oracle
-    o = Oracle(DqlConfig(dtype=dtype), envs, seed=42)
+    o = Oracle(DqlConfig(dtype=dtype, two_axis=two_axis), envs, seed=42)
     o.train_steps(3, 1.0)
     d0 = o.stats_dict()["decisions"]
     t0 = time.perf_counter()
@@ -53,6 +54,7 @@ def main():
     ap.add_argument("--sync-period", type=int, default=32)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--lds-tables", type=int, default=0)
+    ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
-    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0)
+    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis)
     eng = Engine(cfg, args.envs, seed=42, device=local_rank if world > 1 else 0, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
     eng.set_option("lds_tables", args.lds_tables)
@@ -131,24 +133,25 @@ def main():
             if t:
                 traffic = t["hbm_bytes_per_env"] * dec_per_launch
                 traffic_note = "profiles/r1_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction) x env-steps per launch of this run"
-        ach = ALGO_BYTES_PER_ENV_STEP * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        algo_b = ALGO_BYTES_PER_ENV_STEP_2AXIS if args.two_axis else ALGO_BYTES_PER_ENV_STEP
+        ach = algo_b * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.envs} vectorised envs per GPU, x-axis MDP, curriculum step 0, eps {args.eps}, "
+            "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
                                    f"rpm platform r=2 m omega=0.8 rad/s, fused step kernel + int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
                        "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": dec_per_launch,
+                         "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype)
+            out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

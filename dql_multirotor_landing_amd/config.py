@@ -66,7 +66,7 @@ class DqlConfigC(C.Structure):
         ("mp_r_x", C.c_double), ("mp_t_x", C.c_double), ("mp_dt", C.c_double),
         ("mp_top_z", C.c_double), ("mp_half_x", C.c_double), ("mp_half_y", C.c_double), ("drone_bottom", C.c_double),
         ("z_init", C.c_double), ("init_sigma", C.c_double), ("init_uniform", C.c_int32), ("per_env_platform", C.c_int32),
-        ("goal_logic", C.c_int32), ("reserved0", C.c_int32),
+        ("goal_logic", C.c_int32), ("fold_per_step", C.c_int32),
         ("mp_r_lo", C.c_double), ("mp_r_hi", C.c_double), ("mp_t_lo", C.c_double), ("mp_t_hi", C.c_double),
         ("noise_pos_sd", C.c_double), ("noise_vel_sd", C.c_double), ("kalman_q", C.c_double),
     ]
@@ -156,7 +156,7 @@ class DqlConfig:
     init_uniform: int = 0
     per_env_platform: int = 0
     goal_logic: int = 1  # 0 = SimulationMdp.check: no goal / success branch (pkg/mdp.py:784-845)
-    reserved0: int = 0
+    fold_per_step: int = 0  # 1: one alpha step per launch towards the launch's mean target
     mp_r_lo: float = 1.0
     mp_r_hi: float = 3.0
     mp_t_lo: float = 0.8

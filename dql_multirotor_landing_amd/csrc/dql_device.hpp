@@ -201,6 +201,7 @@ template <typename T> struct Env {
   T yw_i, yw_x1, yw_x2, yw_y1, yw_y2, yw_y3, yw_state;
   T pitch_sp, mp_phase, mp_x, mp_u, vf_x, kal_x_x, kal_x_P, shp_p, shp_v, shp_a, cum_x, roll_sp, mp_y;
   T mp_v, vf_y, kal_y_x, kal_y_P, mp_r, mp_w;
+  T shpy_p, shpy_v, shpy_a, cum_y;
   T reward, obs_px, obs_vx, obs_ax, obs_py, obs_vy, obs_ay;
   int idx_x, idx_y, step_count, cur_check, code, flags, action;
 };
@@ -260,7 +261,12 @@ template <typename T, typename K> DQL_DEV T continuous_action(const K& m, T sp, 
 }
 template <typename T>
 DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
-                      T rel_p_y, T abs_p_z) {  // :335-439
+                      T rel_p_y, T abs_p_z, bool two = false, int prev_idy = -1, int cur_idy = -1) {  // :335-439
+  // two-axis configs (beyond the reference, B16): the goal state is the joint goal of both 1-D MDPs
+  const bool goal_x = prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1;
+  const bool goal_y = !two || (prev_idy >= 0 && idx_pos(cur_idy) == 1 && idx_vel(cur_idy) == 1);
+  const bool lvl_x = idx_level(prev_idx) == m.working && idx_level(cur_idx) == m.working;
+  const bool lvl_y = !two || (idx_level(prev_idy) == m.working && idx_level(cur_idy) == m.working);
   step_count += 1;
   if (!(m.quirks & DQL_Q_STICKY_CHECK)) code = DQL_NON_TERMINAL;
   if (contact) code = DQL_TERMINAL_CONTACT;
@@ -269,8 +275,8 @@ DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int cod
   else if (abs_p_z < m.min_alt) code = DQL_TERMINAL_MINIMUM_ALTITUDE;
   else if (abs_p_z > m.p_max) code = DQL_TERMINAL_FLYZONE_Z;
   else if ((T)step_count >= m.timeout_steps) code = DQL_TERMINAL_TIMEOUT;
-  else if (m.goal_logic && prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
-    if (idx_level(prev_idx) == m.working && idx_level(cur_idx) == m.working) {
+  else if (m.goal_logic && goal_x && goal_y) {
+    if (lvl_x && lvl_y) {
       cur_check += 1;
       code = ((T)cur_check >= m.f_ag) ? DQL_TERMINAL_SUCCESS : DQL_NON_TERMINAL_SUCCESS;
     } else {
@@ -479,8 +485,9 @@ DQL_DEV void manager_tick(const SimK<T>& s, Env<T>& e, const T (&R)[9], T cy, T 
 
 struct StepOut {  // what one env contributes to the shared tables / counters this period
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
+  long long target_y_fx;
   long long reward_fx;
-  int cell;             // table cell (idx*3+action) or -1
+  int cell, cell_y;     // table cells (idx*3+action) or -1
   int decision, done;
 };
 
@@ -488,37 +495,52 @@ struct StepOut {  // what one env contributes to the shared tables / counters th
 template <typename T, typename TabPtr>
 DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
                              uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
-  StepOut out; out.cell = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.reward_fx = 0;
+  StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), step_lo = (uint32_t)step_index, step_hi = (uint32_t)((uint64_t)step_index >> 32);
   uint32_t r[4];
   philox4x32(step_lo, step_hi, env_id, STREAM_ACTION, k0, k1, r);
   const bool is_reset = (e.flags & FL_DONE) != 0;
-  const int prev_idx = e.idx_x;
-  int action = 2;
+  const int prev_idx = e.idx_x, prev_idy = e.idx_y;
+  const bool two = s.two_axis != 0;
+  int action = 2, action_y = 2;
+  uint32_t r2[4] = {0u, 0u, 0u, 0u};
+  if (two) philox4x32(step_lo, step_hi, env_id, STREAM_ACTION + 1u, k0, k1, r2);
   if (is_reset) {
-    e.step_count = 0; e.cur_check = 0; e.code = DQL_NON_TERMINAL; e.cum_x = T(0.0);
+    e.step_count = 0; e.cur_check = 0; e.code = DQL_NON_TERMINAL; e.cum_x = T(0.0); e.cum_y = T(0.0);
     e.pitch_sp = T(0.0); e.roll_sp = T(0.0);
-    if (!(s.quirks & DQL_Q_SHAPING_SURVIVES_RESET)) { e.shp_p = T(0.0); e.shp_v = T(0.0); e.shp_a = T(0.0); }
+    if (!(s.quirks & DQL_Q_SHAPING_SURVIVES_RESET)) { e.shp_p = T(0.0); e.shp_v = T(0.0); e.shp_a = T(0.0); e.shpy_p = T(0.0); e.shpy_v = T(0.0); e.shpy_a = T(0.0); }
     T x0;
     if (s.working == 0 && !s.init_uniform) { T n0, n1; box_muller(r[2], r[3], n0, n1); x0 = s.init_sigma * n0; }
     else x0 = fma_(T(2.0) * u24<T>(r[2]), s.p_max, -s.p_max);
     e.p[0] = clip(x0 + e.mp_x, e.mp_x - s.p_max, e.mp_x + s.p_max);
     e.p[1] = T(0.0); e.p[2] = s.z_init;
+    if (two) {
+      T y0;
+      if (s.working == 0 && !s.init_uniform) { T n0, n1; box_muller(r2[2], r2[3], n0, n1); y0 = s.init_sigma * n0; }
+      else y0 = fma_(T(2.0) * u24<T>(r2[2]), s.p_max, -s.p_max);
+      e.p[1] = clip(y0 + e.mp_y, e.mp_y - s.p_max, e.mp_y + s.p_max);
+    }
     e.v[0] = e.v[1] = e.v[2] = T(0.0); e.w[0] = e.w[1] = e.w[2] = T(0.0);
     e.q[0] = T(1.0); e.q[1] = e.q[2] = e.q[3] = T(0.0);
     e.flags &= ~(FL_DONE | FL_CONTACT | FL_OBS_CONTACT);
     e.flags |= FL_WAS_RESET;
   } else {
     e.flags &= ~FL_WAS_RESET;
-    if (mode == MODE_EXTERNAL) action = ext_action;
+    if (mode == MODE_EXTERNAL) { action = ext_action & 3; action_y = two ? (ext_action >> 2) & 3 : 2; }
     else {
       const int greedy = agent_predict(qa, qb, prev_idx);
       const bool explore = (mode == MODE_TRAIN) && ((double)u24<T>(r[0]) < eps);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
+      if (two) {
+        const int greedy_y = agent_predict(qa, qb, prev_idy);
+        const bool explore_y = (mode == MODE_TRAIN) && ((double)u24<T>(r2[0]) < eps);
+        action_y = explore_y ? (int)(((uint64_t)r2[1] * 3u) >> 32) : greedy_y;
+      }
     }
     e.pitch_sp = continuous_action(s, e.pitch_sp, action);
+    if (two) e.roll_sp = -continuous_action(s, -e.roll_sp, action_y);  // theta_y = -roll
   }
-  e.action = action;
+  e.action = action | (two ? action_y << 2 : 0);
   T sp_, cp_, sr_, cr_, B[9];
   det_sincos(e.pitch_sp, sp_, cp_); det_sincos(e.roll_sp, sr_, cr_);
   B[0] = cp_; B[1] = T(0.0); B[2] = sp_;
@@ -548,16 +570,26 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
   int idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
   if (idx < 0) idx = 0;
   e.idx_x = idx;
+  int idy = -1;
+  if (two) {
+    const T roll = det_atan2(R[7], R[8]);
+    idy = discretise(m, e.obs_py, e.obs_vy, e.obs_ay, -roll);
+    if (idy < 0) idy = 0;
+    e.idx_y = idy;
+  }
   e.reward = T(0.0);
   if (is_reset) return out;
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
-  e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2]);
+  e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
   const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
-  e.reward = rew;
+  T rew_y = T(0.0);
+  if (two) rew_y = mdp_reward(m, e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y, e.code, idy, e.obs_py, e.obs_vy, -e.roll_sp);
+  e.reward = two ? rew + rew_y : rew;
   const bool done = e.code <= DQL_TERMINAL_TIMEOUT;
   if (done) e.flags |= FL_DONE;
   out.decision = 1; out.done = done ? 1 : 0;
   out.reward_fx = __double2ll_rn((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  if (two) out.reward_fx += __double2ll_rn((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (mode == MODE_TRAIN) {
     const double q0 = qa[idx * 3], q1 = qa[idx * 3 + 1], q2 = qa[idx * 3 + 2];
     const int b = argmax3(q0, q1, q2);
@@ -568,6 +600,17 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     const double target = (double)rew + (m.gamma * boot) * (double)mask;
     out.cell = prev_idx * 3 + action;
     out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+    if (two) {  // the y transition updates the same shared tables
+      const double y0 = qa[idy * 3], y1 = qa[idy * 3 + 1], y2 = qa[idy * 3 + 2];
+      const int by = argmax3(y0, y1, y2);
+      const double boot_y = by == 0 ? y0 : (by == 1 ? y1 : y2);
+      int mask_y;
+      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
+      else mask_y = !done;
+      const double target_y = (double)rew_y + (m.gamma * boot_y) * (double)mask_y;
+      out.cell_y = prev_idy * 3 + action_y;
+      out.target_y_fx = __double2ll_rn(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+    }
   }
   return out;
 }
@@ -597,6 +640,8 @@ template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict
     const Quad<T> q11 = sr[11 * n + i];
     e.mp_v = q11.a; e.vf_y = q11.b; e.kal_y_x = q11.c; e.kal_y_P = q11.d;
   } else { e.mp_v = T(0.0); e.vf_y = T(0.0); e.kal_y_x = T(0.0); e.kal_y_P = T(1.0); }
+  if (c.two_axis) { const Quad<T> q12 = sr[12 * n + i]; e.shpy_p = q12.a; e.shpy_v = q12.b; e.shpy_a = q12.c; e.cum_y = q12.d; }
+  else { e.shpy_p = e.shpy_v = e.shpy_a = e.cum_y = T(0.0); }
   if (c.per_env_platform) { const Quad<T> q13 = sr[13 * n + i]; e.mp_r = q13.a; e.mp_w = q13.b; }
   else { e.mp_r = c.mp_r; e.mp_w = c.mp_w; }
   e.idx_x = iv.x; e.idx_y = iv.y; e.step_count = iv.z & 0xffff; e.cur_check = (iv.z >> 16) & 0xffff;
@@ -617,6 +662,7 @@ template <typename T> DQL_DEV void store_env(const Env<T>& e, Quad<T>* __restric
   sr[9 * n + i] = Quad<T>{e.kal_x_x, e.kal_x_P, e.shp_p, e.shp_v};
   sr[10 * n + i] = Quad<T>{e.shp_a, e.cum_x, e.roll_sp, e.mp_y};
   if (c.two_axis || c.traj == DQL_TRAJ_EIGHT) sr[11 * n + i] = Quad<T>{e.mp_v, e.vf_y, e.kal_y_x, e.kal_y_P};
+  if (c.two_axis) sr[12 * n + i] = Quad<T>{e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y};
   sr[14 * n + i] = Quad<T>{e.reward, e.obs_px, e.obs_vx, e.obs_ax};
   sr[15 * n + i] = Quad<T>{e.obs_py, e.obs_vy, e.obs_ay, T(0.0)};
   si[i] = make_int4(e.idx_x, e.idx_y, (e.step_count & 0xffff) | (e.cur_check << 16), (e.code & 0xff) | ((e.flags & 0xff) << 8) | ((e.action & 0xff) << 16));

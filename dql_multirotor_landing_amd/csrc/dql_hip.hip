@@ -163,6 +163,7 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
     else o = agent_period(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
     store_env(e, a.sr, a.si, a.n, i, a.c);
     if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
+    if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
     dec = o.decision; don = o.done; rfx = o.reward_fx;
     if (o.done) atomicAdd(&a.stats->by_code[e.code], 1ull);
   }
@@ -186,13 +187,14 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
 }
 
 // mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)), count += m
-DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min) {
+DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
   const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
   const long long c0 = (long long)count[cell];
   double shrink = 1.0;
   long long j = 0;
-  for (; j < m && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
-  long long rem = m - j;
+  const long long m_eff = per_step ? 1 : m;
+  for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
+  long long rem = m_eff - j;
   if (rem > 0) {
     double base = 1.0 - alpha_min, pw = 1.0;
     while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; }
@@ -208,7 +210,7 @@ struct PostArgs {
   long long* window;                 // multi-GPU window accumulators (windowed != 0)
   const double* alpha_tab; int n_tab; double alpha_min;
   Sched* sched; StatsDev* stats; double tick_ratio;  // 1 / (f_ag * dt)
-  int learn, windowed;
+  int learn, windowed, per_step;
 };
 __global__ void k_post(PostArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,7 +219,7 @@ __global__ void k_post(PostArgs a) {
     if (m > 0) {
       if (a.learn) {
         if (a.windowed) { a.window[c] += Tsum; a.window[DQL_N_CELLS + c] += m; }
-        contract_cell(a.qa, a.count, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min);
+        contract_cell(a.qa, a.count, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
       }
       a.accum[c] = 0; a.accum[DQL_N_CELLS + c] = 0;
     }
@@ -229,13 +231,13 @@ __global__ void k_post(PostArgs a) {
     a.stats->agent_steps += 1;
   }
 }
-struct WindowArgs { double* qa_base; double* count_base; double* qa_work; double* count_work; long long* window; const double* alpha_tab; int n_tab; double alpha_min; };
+struct WindowArgs { double* qa_base; double* count_base; double* qa_work; double* count_work; long long* window; const double* alpha_tab; int n_tab; double alpha_min; int per_step; };
 __global__ void k_apply_window(WindowArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= DQL_N_CELLS) return;
   const long long Tsum = a.window[c], m = a.window[DQL_N_CELLS + c];
   if (m > 0) {
-    contract_cell(a.qa_base, a.count_base, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min);
+    contract_cell(a.qa_base, a.count_base, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
     a.window[c] = 0; a.window[DQL_N_CELLS + c] = 0;
   }
   a.qa_work[c] = a.qa_base[c]; a.count_work[c] = a.count_base[c];
@@ -339,7 +341,6 @@ static int check_config(const dql_config* c) {
   if (c->dtype != DQL_F32 && c->dtype != DQL_F64) return fail(DQL_EINVAL, "dtype must be DQL_F32 or DQL_F64");
   if (c->pid_vz[2] != 0.0 || c->pid_yaw[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported by the fused kernel (reference launch files use Kd = 0)");
   if (c->manager_div < 1 || c->dt <= 0 || c->f_ag <= 0) return fail(DQL_EINVAL, "dt, f_ag, manager_div must be positive");
-  if (c->two_axis) return fail(DQL_EINVAL, "two_axis is not implemented in this build");
   if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
   return DQL_OK;
 }
@@ -401,7 +402,7 @@ static int launch_period(dql_ctx* x, int mode, double eps) {
   PostArgs p;
   p.qa = x->qa; p.count = x->count; p.accum = x->accum; p.window = x->window; p.alpha_tab = x->alpha_tab; p.n_tab = x->n_tab;
   p.alpha_min = x->cfg.alpha_min; p.sched = x->sched; p.stats = x->stats; p.tick_ratio = 1.0 / (x->cfg.f_ag * x->cfg.dt);
-  p.learn = (mode == MODE_TRAIN); p.windowed = x->windowed ? 1 : 0;
+  p.learn = (mode == MODE_TRAIN); p.windowed = x->windowed ? 1 : 0; p.per_step = x->cfg.fold_per_step;
   hipLaunchKernelGGL(k_post, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, p);
   x->timer_launches += 1;
   HIP_TRY(hipGetLastError());
@@ -485,7 +486,7 @@ int dql_config_default(dql_config* c) {
   const double pv[6] = {5.0, 10.0, 0.0, 0.0, 10.0, 10.0}, py[6] = {8.0, 1.0, 0.0, -3.141592, 3.141592, 5.0};
   for (int i = 0; i < 6; ++i) { c->pid_vz[i] = pv[i]; c->pid_yaw[i] = py[i]; }
   c->bw_c = 1.0; c->mp_r_x = 2.0; c->mp_t_x = 1.6; c->mp_dt = 0.01; c->mp_top_z = 0.455; c->mp_half_x = 0.55; c->mp_half_y = 0.55; c->drone_bottom = 0.06;
-  c->z_init = 4.0; c->init_sigma = 4.5 / 3; c->init_uniform = 0; c->per_env_platform = 0; c->goal_logic = 1; c->reserved0 = 0;
+  c->z_init = 4.0; c->init_sigma = 4.5 / 3; c->init_uniform = 0; c->per_env_platform = 0; c->goal_logic = 1; c->fold_per_step = 0;
   c->mp_r_lo = 1.0; c->mp_r_hi = 3.0; c->mp_t_lo = 0.8; c->mp_t_hi = 1.6;
   c->noise_pos_sd = 0.0; c->noise_vel_sd = 0.0; c->kalman_q = 1e-4;
   return DQL_OK;
@@ -553,8 +554,9 @@ int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipStreamSynchronize(x->stream)
 int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); *n = x->n; return DQL_OK; }
 int dql_state_bytes_per_env(dql_ctx* x, int64_t* bytes) {
   CHECK_CTX(x);
-  // x-axis: quads 0-10 read + written, quads 14-15 written, int4 read + written
-  *bytes = (int64_t)((11 + 11 + 2) * 4 * x->real_size + 2 * sizeof(int4));
+  // x-axis: quads 0-10 read + written, quads 14-15 written, int4 read + written; two-axis: + quads 11-12
+  const int rw = x->cfg.two_axis ? 13 : 11;
+  *bytes = (int64_t)((rw + rw + 2) * 4 * x->real_size + 2 * sizeof(int4));
   return DQL_OK;
 }
 
@@ -599,6 +601,11 @@ int dql_reset(dql_ctx* x, const uint8_t* mask) {
 int dql_step(dql_ctx* x, const uint8_t* actions) {
   CHECK_CTX(x);
   if (!actions) return fail(DQL_EINVAL, "actions must not be null (use dql_train_steps / dql_eval_steps for on-device action selection)");
+  for (long long i = 0; i < x->n; ++i) {
+    const int ax = actions[i] & 3, ay = (actions[i] >> 2) & 3;
+    if (ax > 2 || ay > 2 || (actions[i] >> 4) || (!x->cfg.two_axis && ay != 0 && ay != 2))
+      return fail(DQL_EINVAL, "action out of range: ax | ay << 2 with ax, ay in 0..2 (ay only in two_axis configs)");
+  }
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipMemcpyAsync(x->d_actions, actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));  // the caller's buffer may be reused right after return
@@ -774,7 +781,7 @@ int dql_apply_accum(dql_ctx* x) {
   CHECK_CTX(x);
   if (!x->windowed) return fail(DQL_ESTATE, "dql_apply_accum needs windowed accumulation (dql_set_windowed)");
   HIP_TRY(hipSetDevice(x->device));
-  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->window, x->alpha_tab, x->n_tab, x->cfg.alpha_min};
+  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->window, x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step};
   hipLaunchKernelGGL(k_apply_window, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, a);
   HIP_TRY(hipGetLastError());
   return DQL_OK;

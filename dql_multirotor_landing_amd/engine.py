@@ -52,8 +52,8 @@ class Engine:
         a = np.ascontiguousarray(actions, dtype=np.uint8)
         if a.shape != (self.n,):
             raise ValueError(f"actions must have shape ({self.n},)")
-        if (a > 2).any():
-            raise ValueError("actions must be 0, 1 or 2")
+        if ((a & 3) > 2).any() or (a >> 4).any() or (((a >> 2) & 3) > 2).any():
+            raise ValueError("actions must be ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold)")
         _lib.check(self.lib.dql_step(self._h, _p(a)))
 
     def reset(self, mask=None):

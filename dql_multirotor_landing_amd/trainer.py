@@ -33,7 +33,8 @@ class Trainer:
                  gamma: float = 0.99, scale_modification_value=(0.8172650252856599, 0.8211253690681617, 0.8257273369742982, 0.8311571820651724),
                  t_max: int = 20, z_init: float = 4.0, f_ag: float = 22.92, p_max: float = 4.5,
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
-                 checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True) -> None:
+                 checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
+                 fold_per_step: int = 0, eps_floor: float = 0.0) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -59,6 +60,7 @@ class Trainer:
         self._n_envs, self._device, self._dtype, self._mode = int(n_envs), device, dtype, mode
         self._chunk_steps, self._checkpoint_every, self._quiet = int(chunk_steps), int(checkpoint_every), quiet
         self._max_steps_per_level = max_steps_per_level
+        self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
         self.history = []  # one record per finished curriculum level
         self._engine: Optional[Engine] = None
 
@@ -134,7 +136,7 @@ class Trainer:
     def _config(self, level: int) -> DqlConfig:
         return DqlConfig(working_curriculum_step=level, dtype=self._dtype, quirks=Q_REFERENCE if self._mode == "reference" else Q_PAPER,
                          t_max=self._t_max, z_init=self._z_init, f_ag=self._f_ag, p_max=self._p_max, init_sigma=self._p_max / 3,
-                         gamma=self._gamma, alpha_min=self._alpha_min, alpha_omega=self._omega)
+                         gamma=self._gamma, alpha_min=self._alpha_min, alpha_omega=self._omega, fold_per_step=self._fold_per_step)
 
     def _push_tables(self):
         a = self._double_q_learning_agent
@@ -168,7 +170,7 @@ class Trainer:
             info: Dict[str, Any] = {}
             chunk_i = 0
             while episodes < self._max_num_episodes:
-                eps = self.exploration_rate(episodes, k)
+                eps = max(self.exploration_rate(episodes, k), self._eps_floor)  # eps_floor = 0 is the reference schedule
                 eng.train_steps(self._chunk_steps, eps)
                 steps += self._chunk_steps
                 s = eng.stats()

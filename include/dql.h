@@ -108,7 +108,8 @@ typedef struct dql_config {
   int32_t init_uniform;         /* 0: N(0,sigma) at level 0 else U (TrainingLandingEnv.reset); 1: always U (Simulation env) */
   int32_t per_env_platform;     /* 1: r_x, t_x drawn per env from the ranges below (BASELINE config 5) */
   int32_t goal_logic;           /* 1: TrainingMdp.check goal / success branch (pkg/mdp.py:402-425); 0: SimulationMdp.check (:784-845) */
-  int32_t reserved0;
+  int32_t fold_per_step;        /* 0: per-visit fold (prod of (1-alpha) over the m visits of a launch); 1: ONE alpha step per launch towards the
+                                   launch's mean target (count still advances by m): smoother at large N */
   double mp_r_lo, mp_r_hi, mp_t_lo, mp_t_hi;
   double noise_pos_sd, noise_vel_sd, kalman_q; /* scripts/manager_node.py:83-98 */
 } dql_config;

@@ -315,7 +315,12 @@ static inline REAL continuous_action(const mdpc_t* m, REAL sp, int action) {
 }
 /* pkg/mdp.py:335-439.  Returns the (possibly sticky) check code. */
 static int mdp_check(const mdpc_t* m, int* step_count, int* cur_check, int code, int prev_idx, int cur_idx, int contact,
-                     REAL rel_p_x, REAL rel_p_y, REAL abs_p_z) {
+                     REAL rel_p_x, REAL rel_p_y, REAL abs_p_z, int two, int prev_idy, int cur_idy) {
+  /* two-axis configs (beyond the reference, B16): the goal state is the joint goal of both 1-D MDPs */
+  const int goal_x = prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1;
+  const int goal_y = !two || (prev_idy >= 0 && idx_pos(cur_idy) == 1 && idx_vel(cur_idy) == 1);
+  const int lvl_x = idx_level(prev_idx) == m->working && idx_level(cur_idx) == m->working;
+  const int lvl_y = !two || (idx_level(prev_idy) == m->working && idx_level(cur_idy) == m->working);
   *step_count += 1;
   if (!(m->quirks & DQL_Q_STICKY_CHECK)) code = DQL_NON_TERMINAL;
   if (contact) code = DQL_TERMINAL_CONTACT;
@@ -324,8 +329,8 @@ static int mdp_check(const mdpc_t* m, int* step_count, int* cur_check, int code,
   else if (abs_p_z < m->min_alt) code = DQL_TERMINAL_MINIMUM_ALTITUDE;
   else if (abs_p_z > m->p_max) code = DQL_TERMINAL_FLYZONE_Z;
   else if ((REAL)*step_count >= m->timeout_steps) code = DQL_TERMINAL_TIMEOUT;
-  else if (m->goal_logic && prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1) {
-    if (idx_level(prev_idx) == m->working && idx_level(cur_idx) == m->working) {
+  else if (m->goal_logic && goal_x && goal_y) {
+    if (lvl_x && lvl_y) {
       *cur_check += 1;
       code = ((REAL)*cur_check >= m->f_ag) ? DQL_TERMINAL_SUCCESS : DQL_NON_TERMINAL_SUCCESS;
     } else {
@@ -600,8 +605,10 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   uint32_t r[4];
   philox4x32(step_lo, step_hi, env_id, STREAM_ACTION, k0, k1, r);
   const int is_reset = (e->flags & FL_DONE) != 0;
-  const int prev_idx = e->idx[0];
-  int action = 2;
+  const int prev_idx = e->idx[0], prev_idy = e->idx[1], two = s->two_axis;
+  int action = 2, action_y = 2;
+  uint32_t r2[4] = {0u, 0u, 0u, 0u};
+  if (two) philox4x32(step_lo, step_hi, env_id, STREAM_ACTION + 1u, k0, k1, r2); /* y axis: same draws on its own stream */
   if (is_reset) {
     /* TrainingMdp.reset (pkg/mdp.py:562-569, 194-200) */
     e->step_count = 0; e->cur_check = 0; e->code = DQL_NON_TERMINAL; e->cum[0] = R_(0.0); e->cum[1] = R_(0.0);
@@ -613,22 +620,35 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
     else x0 = FMA(R_(2.0) * u24(r[2]), s->p_max, -s->p_max);
     e->p[0] = clip(x0 + e->mp_x, e->mp_x - s->p_max, e->mp_x + s->p_max);
     e->p[1] = R_(0.0); e->p[2] = s->z_init;
+    if (two) { /* the reference multiplies its y offset by 0 (B16); the 2-axis configs fly it */
+      REAL y0;
+      if (s->working == 0 && !s->init_uniform) { REAL n0, n1; box_muller(r2[2], r2[3], &n0, &n1); y0 = s->init_sigma * n0; }
+      else y0 = FMA(R_(2.0) * u24(r2[2]), s->p_max, -s->p_max);
+      e->p[1] = clip(y0 + e->mp_y, e->mp_y - s->p_max, e->mp_y + s->p_max);
+    }
     e->v[0] = e->v[1] = e->v[2] = R_(0.0); e->w[0] = e->w[1] = e->w[2] = R_(0.0);
     e->q[0] = R_(1.0); e->q[1] = e->q[2] = e->q[3] = R_(0.0);
     e->flags &= ~(FL_DONE | FL_CONTACT | FL_OBS_CONTACT); /* scripts/manager_node.py:330 */
     e->flags |= FL_WAS_RESET;
   } else {
     e->flags &= ~FL_WAS_RESET;
-    if (mode == 2) action = ext_action[0];
+    if (mode == 2) { action = ext_action[0] & 3; action_y = two ? (ext_action[0] >> 2) & 3 : 2; }
     else {
       /* guess (pkg/double_q_learning.py:110-117) */
       const int greedy = agent_predict(qa, qb, prev_idx);
       const int explore = (mode == 0) && ((double)u24(r[0]) < eps);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
+      if (two) {
+        const int greedy_y = agent_predict(qa, qb, prev_idy);
+        const int explore_y = (mode == 0) && ((double)u24(r2[0]) < eps);
+        action_y = explore_y ? (int)(((uint64_t)r2[1] * 3u) >> 32) : greedy_y;
+      }
     }
     e->pitch_sp = continuous_action(m, e->pitch_sp, action);
+    /* y-axis angle theta_y = -roll: a positive theta_y accelerates the drone towards +y, as a positive pitch does towards +x */
+    if (two) e->roll_sp = -continuous_action(m, -e->roll_sp, action_y);
   }
-  e->action = action;
+  e->action = action | (two ? action_y << 2 : 0);
   /* B = Rx(roll_sp) Ry(pitch_sp) (pkg/attitude_controller.py:138-140) */
   REAL sp_, cp_, sr_, cr_, B[9];
   det_sincos(e->pitch_sp, &sp_, &cp_); det_sincos(e->roll_sp, &sr_, &cr_);
@@ -657,16 +677,26 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   int idx = discretise(m, e->obs[0], e->obs[2], e->obs[4], pitch);
   if (idx < 0) idx = 0; /* only reachable through NaN; the reference raises ValueError there */
   e->idx[0] = idx;
+  int idy = -1;
+  if (two) {
+    const REAL roll = det_atan2(R[7], R[8]);
+    idy = discretise(m, e->obs[1], e->obs[3], e->obs[5], -roll);
+    if (idy < 0) idy = 0;
+    e->idx[1] = idy;
+  }
   e->reward = R_(0.0);
   if (is_reset) return;
   const int contact = (e->flags & FL_OBS_CONTACT) != 0;
-  e->code = mdp_check(m, &e->step_count, &e->cur_check, e->code, prev_idx, idx, contact, e->obs[0], e->obs[1], e->p[2]);
-  const REAL rew = mdp_reward(m, e->shp[0], &e->cum[0], e->code, idx, e->obs[0], e->obs[2], e->pitch_sp);
-  e->reward = rew;
+  e->code = mdp_check(m, &e->step_count, &e->cur_check, e->code, prev_idx, idx, contact, e->obs[0], e->obs[1], e->p[2], two, prev_idy, idy);
+  REAL rew = mdp_reward(m, e->shp[0], &e->cum[0], e->code, idx, e->obs[0], e->obs[2], e->pitch_sp);
+  REAL rew_y = R_(0.0);
+  if (two) rew_y = mdp_reward(m, e->shp[1], &e->cum[1], e->code, idy, e->obs[1], e->obs[3], -e->roll_sp);
+  e->reward = two ? rew + rew_y : rew;
   const int done = e->code <= DQL_TERMINAL_TIMEOUT;
   if (done) e->flags |= FL_DONE;
   st->decisions += 1;
   st->reward_fx += llrint((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  if (two) st->reward_fx += llrint((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (done) { st->episodes += 1; st->by_code[e->code] += 1; }
   if (mode == 0) {
     /* TD target of _update_q_table (pkg/double_q_learning.py:136-145), accumulated in fixed point */
@@ -679,6 +709,17 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
     const int cell = prev_idx * 3 + action;
     accum[cell] += llrint(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
     accum[DQL_N_CELLS + cell] += 1;
+    if (two) { /* the y transition updates the same shared tables (scripts/simulation.py:15-16 loads one table pair for both axes) */
+      const double* qy = qa + idy * 3;
+      const double boot_y = qy[argmax3(qy[0], qy[1], qy[2])];
+      int mask_y;
+      if (s->quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
+      else mask_y = !done;
+      const double target_y = (double)rew_y + (gamma * boot_y) * (double)mask_y;
+      const int cell_y = prev_idy * 3 + action_y;
+      accum[cell_y] += llrint(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      accum[DQL_N_CELLS + cell_y] += 1;
+    }
   }
 }
 
@@ -774,7 +815,7 @@ EXPORT void ORC(mdp_transition)(const dql_config* c, int64_t n, const uint8_t* a
     const REAL pitch = (REAL)obs[4 * n + i], z = (REAL)obs[5 * n + i]; const int contact = obs[6 * n + i] != 0.0;
     const int idx = discretise(&m, px, vx, ax, pitch);
     idx_out[i] = idx;
-    code = mdp_check(&m, &step_count, &cur_check, code, prev_idx[i], idx, contact, px, py, z);
+    code = mdp_check(&m, &step_count, &cur_check, code, prev_idx[i], idx, contact, px, py, z, 0, -1, -1);
     const REAL rew = mdp_reward(&m, shp, &cum, code, idx, px, vx, sp);
     reward_out[i] = rew; done_out[i] = code <= DQL_TERMINAL_TIMEOUT;
     ms[0 * n + i] = sp; ms[1 * n + i] = shp[0]; ms[2 * n + i] = shp[1]; ms[3 * n + i] = shp[2]; ms[4 * n + i] = cum;
@@ -871,15 +912,16 @@ EXPORT void orc_transfer(double* qa, double* qb, int k, double ratio, int n_leve
 /* batched table update: for every cell visited m times with mean target tbar,
  *   Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)),  count += m
  * (m = 1 is the reference's Q += alpha (target - Q)); alpha(c) = alpha_tab[c] for c < n_tab, alpha_min beyond */
-EXPORT void orc_apply_accum(double* qa, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min) {
+EXPORT void orc_apply_accum(double* qa, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min, int per_step) {
   for (int cell = 0; cell < DQL_N_CELLS; ++cell) {
     const int64_t m = accum[DQL_N_CELLS + cell];
     if (m <= 0) continue;
     const double tbar = ((double)accum[cell] * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
     const int64_t c0 = (int64_t)count[cell];
     double shrink = 1.0; int64_t j = 0;
-    for (; j < m && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
-    int64_t rem = m - j;
+    const int64_t m_eff = per_step ? 1 : m;
+    for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
+    int64_t rem = m_eff - j;
     if (rem > 0) { double base = 1.0 - alpha_min, pw = 1.0; while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; } shrink *= pw; }
     qa[cell] = tbar + (qa[cell] - tbar) * shrink;
     count[cell] += (double)m;

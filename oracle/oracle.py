@@ -115,7 +115,7 @@ class Oracle:
 
     def _contract(self, qa, count, accum):
         lib().orc_apply_accum(_p(qa), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
-                              C.c_double(self.cfg.alpha_min))
+                              C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step))
 
     # ---- windowed (multi-rank) semantics: same interface as the product Engine ----
     def set_windowed(self, on: bool):

@@ -21,12 +21,14 @@ if __name__ == "__main__":
     ap.add_argument("--max-steps-per-level", type=int, default=None)
     ap.add_argument("--max-episodes", type=int, default=50000)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--fold-per-step", type=int, default=0)
+    ap.add_argument("--eps-floor", type=float, default=0.0)
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build_hip()
     from dql_multirotor_landing_amd.config import F32, F64
     from dql_multirotor_landing_amd.trainer import Trainer
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose)
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor)
     hist = tr.curriculum_training()
     print(json.dumps({"history": hist, "save_path": str(tr._save_path)}, indent=1))

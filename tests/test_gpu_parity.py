@@ -71,6 +71,8 @@ def test_long_run_with_episode_ends(mods):
     dict(working_curriculum_step=2), dict(working_curriculum_step=4, init_uniform=1, vz_setpoint=-0.4),
     dict(quirks=Q_PAPER), dict(trajectory=TRAJ_EIGHT), dict(per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1),
     dict(lds=1), dict(block=256), dict(block=128, lds=1),
+    dict(two_axis=1), dict(two_axis=1, working_curriculum_step=3, init_uniform=1), dict(two_axis=1, quirks=Q_PAPER, trajectory=TRAJ_EIGHT),
+    dict(two_axis=1, goal_logic=0, vz_setpoint=-0.4, working_curriculum_step=4, init_uniform=1),
 ])
 def test_config_variants_bit_exact(mods, kw):
     Engine, Oracle = mods
@@ -198,3 +200,21 @@ def test_rccl_reducer_world_size_1():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_two_axis_bit_exact_f64_and_external_actions(mods):
+    """BASELINE configs[2]: joint x+y MDP (two 1-D MDPs per env on shared tables, roll channel flown)."""
+    Engine, Oracle = mods
+    n = 384
+    eng = Engine(DqlConfig(dtype=F64, two_axis=1), n, seed=17)
+    orc = Oracle(DqlConfig(dtype=F64, two_axis=1), n, seed=17)
+    eng.train_steps(120, 0.6); orc.train_steps(120, 0.6)
+    _compare(eng, orc, exact=True, what="two axis f64")
+    st = eng.stats()
+    assert st["by_code"]["TERMINAL_FLYZONE_Y"] > 0, "the y axis is really flown"
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        a = (rng.integers(0, 3, n) | (rng.integers(0, 3, n) << 2)).astype(np.uint8)
+        eng.step(a); orc.step(a)
+    _compare(eng, orc, exact=True, what="two axis external actions")
+    assert eng.state_bytes_per_env() > Engine(DqlConfig(dtype=F64), 4, seed=1).state_bytes_per_env()
