@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--lds-tables", type=int, default=0)
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the multi-rank path on fewer GPUs (host-side exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
@@ -74,19 +75,24 @@ def main():
     import __graft_entry__ as g
     g.build_hip()
     from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
-    from dql_multirotor_landing_amd.dist import ShardedRunner, TorchWindowReducer
+    from dql_multirotor_landing_amd.dist import HostWindowReducer, ShardedRunner, TorchWindowReducer
     from dql_multirotor_landing_amd.engine import Engine
 
     dtype = F32 if args.dtype == "f32" else F64
+    dev_index = local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        if args.backend == "gloo":
+            dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis)
-    eng = Engine(cfg, args.envs, seed=42, device=local_rank if world > 1 else 0, env_id_offset=rank * args.envs)
+    eng = Engine(cfg, args.envs, seed=42, device=dev_index if world > 1 else 0, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
     eng.set_option("lds_tables", args.lds_tables)
-    reducer = TorchWindowReducer(eng, local_rank) if world > 1 else None
+    reducer = None
+    if world > 1:
+        reducer = TorchWindowReducer(eng, dev_index) if args.backend == "nccl" else HostWindowReducer(eng)
     runner = ShardedRunner(eng, reducer, sync_period=args.sync_period)
 
     def barrier():
@@ -119,7 +125,7 @@ def main():
     dec_per_launch = (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])
 
     if world > 1:
-        t = torch.tensor([wall, float(decisions)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([wall, float(decisions)], dtype=torch.float64, device=f"cuda:{dev_index}" if args.backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall = float(tmax[0]); decisions = int(tsum[1])

@@ -23,6 +23,12 @@
 #include "../../include/dql.h"
 
 #define DQL_DEV __device__ __forceinline__
+// -DDQL_MARK: section markers in the ISA listing (tools/isa_sections.py); never defined in the shipped build
+#ifdef DQL_MARK
+#define DQL_SECTION(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; SECTION " name ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DQL_SECTION(name) do { } while (0)
+#endif
 
 namespace dql {
 
@@ -31,7 +37,17 @@ namespace dql {
 // ---------------------------------------------------------------------------------------------
 DQL_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DQL_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-DQL_DEV float sqrt_(float a) { return __builtin_sqrtf(a); }
+// Correctly rounded sqrt for x = 0 or normal x (the only inputs this kernel produces): hardware v_sqrt_f32 (<= 1 ulp) plus the
+// neighbour test LLVM's own expansion uses, without its denormal rescaling and inf/nan class test (9 instead of 18
+// instructions; x = 0 falls through: the lower neighbour is NaN and the upper one gives fma(-tiny, 0, 0) = -0, both compares false).
+DQL_DEV float sqrt_(float x) {
+  float y = __builtin_amdgcn_sqrtf(x);
+  const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+  const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+  y = (rm <= 0.0f) ? ym : y;
+  y = (rp > 0.0f) ? yp : y;
+  return y;
+}
 DQL_DEV double sqrt_(double a) { return __builtin_sqrt(a); }
 DQL_DEV float abs_(float a) { return __builtin_fabsf(a); }
 DQL_DEV double abs_(double a) { return __builtin_fabs(a); }
@@ -359,11 +375,19 @@ template <typename T> DQL_DEV void quat_to_R(const T (&q)[4], T (&R)[9]) {
   R[3] = T(2.0) * (xy + wz); R[4] = T(1.0) - T(2.0) * (xx + zz); R[5] = T(2.0) * (yz - wx);
   R[6] = T(2.0) * (xz - wy); R[7] = T(2.0) * (yz + wx); R[8] = T(1.0) - T(2.0) * (xx + yy);
 }
+// cos / sin of yaw = atan2(R10, R00): (R00, R10) / sqrt(R00^2 + R10^2).  n2 = cos^2(tilt out of the horizontal) is close
+// to 1 in flight, so 1/sqrt(n2) is Newton's iteration from r0 = 1.5 - 0.5 n2 (multiplies and fmas only; converged to
+// rounding for tilt < ~55 deg, degrades gracefully — never NaN — for a tumbling vehicle)
+template <typename T> struct YawIters;
+template <> struct YawIters<float> { static constexpr int n = 4; };
+template <> struct YawIters<double> { static constexpr int n = 5; };
 template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
   const T n2 = fma_(R[0], R[0], R[3] * R[3]);
-  if (n2 < T(1e-12)) { c = T(1.0); s = T(0.0); return; }
-  const T inv = T(1.0) / sqrt_(n2);
-  c = R[0] * inv; s = R[3] * inv;
+  const T h = T(-0.5) * n2;
+  T r = fma_(T(-0.5), n2, T(1.5));
+#pragma unroll
+  for (int k = 0; k < YawIters<T>::n; ++k) r = r * fma_(h * r, r, T(1.5));
+  c = R[0] * r; s = R[3] * r;
 }
 // attitude_controller.py:107-156
 template <typename T>
@@ -551,17 +575,24 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
   for (int i = 0; i < n_ticks; ++i) {
+    DQL_SECTION("rot");
     quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+    DQL_SECTION("manager");
     if (phase == 0) { manager_tick(s, e, R, cy, sy, mgr_index, k0, k1, step_lo, step_hi, env_id, mgr_in_step); ++mgr_in_step; ++mgr_index; }
     phase = (phase + 1 == s.div) ? 0 : phase + 1;
+    DQL_SECTION("pid");
     const T thrust = pid_output(s, s.vz_kp, s.vz_ki, s.vz_lo, s.vz_hi, s.vz_wind, s.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
     const T r_cmd = pid_output(s, s.yw_kp, s.yw_ki, s.yw_lo, s.yw_hi, s.yw_wind, s.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
+    DQL_SECTION("attitude");
     attitude(s, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
+    DQL_SECTION("motor_body");
     motor_and_body(s, e, R, cmd);
+    DQL_SECTION("platform_contact");
     e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
     if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
   }
+  DQL_SECTION("epilogue");
   asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the loop
   const MdpK<T> m = *mp;
   quat_to_R(e.q, R);

@@ -466,11 +466,14 @@ static inline void quat_to_R(const REAL* q, REAL R[9]) {
   R[6] = R_(2.0) * (xz - wy); R[7] = R_(2.0) * (yz + wx); R[8] = R_(1.0) - R_(2.0) * (xx + yy);
 }
 /* cos/sin of yaw = atan2(R10, R00) without the angle (pkg/attitude_controller.py:136-137) */
+/* n2 = cos^2(tilt) is close to 1 in flight: 1/sqrt(n2) by Newton's iteration from r0 = 1.5 - 0.5 n2 (multiplies and fmas
+ * only; converged to rounding for tilt < ~55 deg, degrades gracefully, never NaN, for a tumbling vehicle) */
 static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) {
   const REAL n2 = FMA(R[0], R[0], R[3] * R[3]);
-  if (n2 < R_(1e-12)) { *c = R_(1.0); *s = R_(0.0); return; }
-  const REAL inv = R_(1.0) / SQRT(n2);
-  *c = R[0] * inv; *s = R[3] * inv;
+  const REAL h = R_(-0.5) * n2;
+  REAL r = FMA(R_(-0.5), n2, R_(1.5));
+  for (int k = 0; k < (ORACLE_F32 ? 4 : 5); ++k) r = r * FMA(h * r, r, R_(1.5));
+  *c = R[0] * r; *s = R[3] * r;
 }
 
 /* pkg/attitude_controller.py:107-156: (R, body rates, B = Rx(roll_sp) Ry(pitch_sp), yaw rate cmd, thrust) -> rotor speed commands */

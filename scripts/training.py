@@ -23,12 +23,13 @@ if __name__ == "__main__":
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--fold-per-step", type=int, default=0)
     ap.add_argument("--eps-floor", type=float, default=0.0)
+    ap.add_argument("--success-rate", type=float, default=0.96, help="promotion threshold (reference: 0.96, pkg/trainer.py:25)")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build_hip()
     from dql_multirotor_landing_amd.config import F32, F64
     from dql_multirotor_landing_amd.trainer import Trainer
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor)
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
     hist = tr.curriculum_training()
     print(json.dumps({"history": hist, "save_path": str(tr._save_path)}, indent=1))

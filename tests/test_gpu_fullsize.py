@@ -1,0 +1,94 @@
+"""Full-size (BASELINE.json configs) checks on the GPU through size-independent properties — the CPU oracle cannot
+run a million envs in seconds, so here the product is checked against itself and against conservation laws:
+  * run-to-run determinism (integer accumulators make the atomics order independent),
+  * shard invariance: 4 shards x 262 144 envs (BASELINE configs[3]/[4] per-GPU sizes) with the window accumulators summed by
+    hand every step == one engine of 1 048 576 envs, bit for bit (what the RCCL all-reduce does on 8 GPUs with sync_period 1),
+  * conservation: visits added to state_action_counter == env-steps (x2 in the 2-axis config), terminal histogram == episodes,
+  * a sample of the big run equals the oracle stepping the same global env ids while both read the same tables."""
+import numpy as np
+import pytest
+
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from dql_multirotor_landing_amd.engine import Engine
+    return Engine
+
+
+def _tables(e):
+    qa, qb, cnt = e.get_tables()
+    return qa.ravel().copy(), cnt.ravel().copy()
+
+
+def test_determinism_and_conservation_65536(Engine):
+    """BASELINE configs[2] size."""
+    out = []
+    for _ in range(2):
+        e = Engine(DqlConfig(dtype=F32), 65536, seed=2025)
+        e.train_steps(60, 0.7)
+        qa, cnt = _tables(e)
+        st = e.stats()
+        out.append((qa, cnt, e.states().copy(), st))
+        e.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    st = out[0][3]
+    assert out[0][1].sum() == st["decisions"] > 60 * 65536 * 0.9
+    assert sum(st["by_code"].values()) == st["episodes"] > 0
+
+
+def test_two_axis_conservation_65536(Engine):
+    e = Engine(DqlConfig(dtype=F32, two_axis=1), 65536, seed=7)
+    e.train_steps(40, 1.0)
+    _, cnt = _tables(e)
+    st = e.stats()
+    assert cnt.sum() == 2 * st["decisions"]
+    assert st["by_code"]["TERMINAL_FLYZONE_Y"] > 0
+    e.close()
+
+
+def test_shard_invariance_1m_envs(Engine):
+    n_total, shards, steps = 1 << 20, 4, 12
+    cfg = lambda: DqlConfig(dtype=F32)
+    whole = Engine(cfg(), n_total, seed=99)
+    whole.train_steps(steps, 0.5)
+    parts = [Engine(cfg(), n_total // shards, seed=99, env_id_offset=k * (n_total // shards)) for k in range(shards)]
+    for p in parts:
+        p.set_windowed(True)
+    for _ in range(steps):
+        for p in parts:
+            p.train_steps(1, 0.5)
+        tot = sum(p.get_accum() for p in parts)  # = all-reduce(sum) of the int64 window accumulators
+        for p in parts:
+            p.set_accum(tot); p.apply_accum()
+    qa_w, cnt_w = _tables(whole)
+    for p in parts:
+        qa_p, cnt_p = _tables(p)
+        np.testing.assert_array_equal(qa_p, qa_w)
+        np.testing.assert_array_equal(cnt_p, cnt_w)
+    np.testing.assert_array_equal(np.concatenate([p.states() for p in parts]), whole.states())
+    r_w = whole.rewards()
+    np.testing.assert_array_equal(np.concatenate([p.rewards() for p in parts]), r_w)
+    dw = whole.stats()["decisions"]
+    assert sum(p.stats()["decisions"] for p in parts) == dw == int(cnt_w.sum())
+    # a slice of the big run against the oracle on the same global env ids, both reading the big run's tables
+    from oracle.oracle import Oracle
+    lo, m = 777_000, 256
+    orc = Oracle(cfg(), m, seed=99, env_id_offset=lo)
+    ref = Engine(cfg(), n_total, seed=99)
+    for _ in range(steps):
+        qa, qb, cnt = ref.get_tables()
+        orc.qa[:] = qa.ravel(); orc.qb[:] = qb.ravel(); orc.count[:] = cnt.ravel()
+        ref.train_steps(1, 0.5)
+        orc._period(0, 0.5); orc.accum[:] = 0
+    reals, ints = ref.get_fields()
+    o_r, o_i = orc.get_fields()
+    np.testing.assert_array_equal(ints[:, lo:lo + m], o_i)
+    np.testing.assert_array_equal(reals[:, lo:lo + m], o_r)
+    for e in parts + [whole, ref]:
+        e.close()
