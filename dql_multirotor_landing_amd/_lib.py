@@ -66,7 +66,6 @@ SYMBOLS = {
     "dql_timer_stop": (C.c_int, [_vp, C.POINTER(_dbl)]),
     "dql_kernel_timer": (C.c_int, [_vp, _i32]),
     "dql_kernel_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
-    "dql_use_graph": (C.c_int, [_vp, _i32]),
     "dql_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "dql_discretise": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -192,7 +192,7 @@ template <typename T> struct MdpK {
 };
 // SimK: constants of the physics tick loop (kernel argument by value).
 template <typename T> struct SimK {
-  T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, aup, adn, omax, cd, crd;
+  T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -344,7 +344,9 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // filters / PID  (pkg/filters.py, pkg/pid.py)
 // ---------------------------------------------------------------------------------------------
 template <typename T> DQL_DEV T butterworth(const SimK<T>& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
-  const T value = c.bw_inv * (x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3 - (c.bw_k2 * y2));
+  T acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
+  if (c.bw_k2 != T(0.0)) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
+  const T value = c.bw_inv * acc;
   x2 = x1; x1 = x0;
   y3 = y2; y2 = y1; y1 = value;
   return value;
@@ -359,7 +361,7 @@ DQL_DEV T pid_output(const SimK<T>& c, T kp, T ki, T lo, T hi, T wind, T sp, T s
 }
 template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z) {  // filters.py:19-36
   P += Q;
-  const T K = P / (P + Rm);
+  const T K = (Rm == T(0.0)) ? T(1.0) : P / (P + Rm);  // P / (P + 0) is exactly 1
   x += K * (z - x);
   P *= (T(1.0) - K);
   return x;
@@ -412,19 +414,21 @@ DQL_DEV void attitude(const SimK<T>& s, const T (&R)[9], const T (&w)[3], const 
 template <typename T> DQL_DEV void motor_and_body(const SimK<T>& s, Env<T>& e, const T (&R)[9], const T (&cmd)[4]) {
   const T l = s.l, h = s.h;
   const T w0 = e.w[0], w1 = e.w[1], w2 = e.w[2];
-  const T T0 = s.kf * e.om[0] * e.om[0], T1 = s.kf * e.om[1] * e.om[1], T2 = s.kf * e.om[2] * e.om[2], T3 = s.kf * e.om[3] * e.om[3];
+  // thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
+  const T q0 = e.om[0] * e.om[0], q1 = e.om[1] * e.om[1], q2 = e.om[2] * e.om[2], q3 = e.om[3] * e.om[3];
+  const T Fbz = s.kf * ((q0 + q1) + (q2 + q3));
+  T tx = s.lkf * (q1 - q3), ty = s.lkf * (q2 - q0), tz = s.kmkf * ((q0 - q1) + (q2 - q3));
+  // rotor drag -|om_i| c_d v_perp,i with v_perp,i = (v_body + w x r_i) restricted to the rotor plane, summed in closed form:
+  // sum_i om_i (w x r_i)_x = S w_y h - w_z l (om1 - om3),  sum_i om_i (w x r_i)_y = -S w_x h + w_z l (om0 - om2)
   const T vbx = fma_(R[0], e.v[0], fma_(R[3], e.v[1], R[6] * e.v[2]));
   const T vby = fma_(R[1], e.v[0], fma_(R[4], e.v[1], R[7] * e.v[2]));
   const T uxc = fma_(w1, h, vbx), uyc = fma_(-w0, h, vby), wzl = w2 * l;
-  const T ux[4] = {uxc, uxc - wzl, uxc, uxc + wzl};
-  const T uy[4] = {uyc + wzl, uyc, uyc - wzl, uyc};
-  T dx[4], dy[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const T k = -(s.cd * e.om[i]); dx[i] = k * ux[i]; dy[i] = k * uy[i]; }
-  const T Fbx = (dx[0] + dx[1]) + (dx[2] + dx[3]), Fby = (dy[0] + dy[1]) + (dy[2] + dy[3]), Fbz = (T0 + T1) + (T2 + T3);
-  T tx = l * (T1 - T3), ty = l * (T2 - T0), tz = s.km * ((T0 - T1) + (T2 - T3));
-  tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, (dy[0] - dy[2]) - (dx[1] - dx[3]), tz);
-  tx = fma_(s.crd, Fbx, tx); ty = fma_(s.crd, Fby, ty);
+  const T S = (e.om[0] + e.om[1]) + (e.om[2] + e.om[3]), d02 = e.om[0] - e.om[2], d13 = e.om[1] - e.om[3];
+  const T Fbx = -(s.cd * fma_(S, uxc, -(wzl * d13)));
+  const T Fby = -(s.cd * fma_(S, uyc, wzl * d02));
+  const T tzd = -(s.cd * fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))));  // sum_i (r_i x drag_i)_z / l
+  tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, tzd, tz);
+  tx = fma_(s.crd, Fbx, tx); ty = fma_(s.crd, Fby, ty);  // rolling moment = (c_r / c_d) * drag force
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const T ref = cmd[i] < s.omax ? cmd[i] : s.omax;

@@ -59,7 +59,7 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   memset(&d, 0, sizeof(d));
   d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
   for (int i = 0; i < 3; ++i) { d.I[i] = (T)c.inertia[i]; d.inv_I[i] = (T)(1.0 / c.inertia[i]); d.kR[i] = (T)c.k_R[i]; d.kW[i] = (T)c.k_W[i]; }
-  d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m;
+  d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m; d.lkf = (T)(c.arm_length * c.k_f); d.kmkf = (T)(c.k_m * c.k_f);
   d.aup = (T)c.rotor_alpha_up; d.adn = (T)c.rotor_alpha_down; d.omax = (T)c.rotor_max; d.cd = (T)c.c_drag; d.crd = (T)(c.c_roll / c.c_drag);
   d.ia = (T)(1.0 / (4.0 * c.k_f)); d.ib = (T)(1.0 / (2.0 * c.arm_length * c.k_f)); d.ic = (T)(1.0 / (4.0 * c.k_f * c.k_m));
   d.vz_kp = (T)c.pid_vz[0]; d.vz_ki = (T)c.pid_vz[1]; d.vz_lo = (T)c.pid_vz[3]; d.vz_hi = (T)c.pid_vz[4]; d.vz_wind = (T)c.pid_vz[5]; d.vz_sp = (T)c.vz_setpoint;
@@ -332,7 +332,6 @@ struct dql_ctx {
   bool windowed = false;
   int lds_tables = 0;
   int block = 0;  // 0 = auto
-  bool use_graph = false;
 };
 
 static int check_config(const dql_config* c) {
@@ -856,7 +855,6 @@ int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
   if (launches) *launches = n;
   return DQL_OK;
 }
-int dql_use_graph(dql_ctx* x, int32_t enable) { CHECK_CTX(x); x->use_graph = enable != 0; return DQL_OK; }
 int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");

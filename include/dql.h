@@ -200,7 +200,6 @@ int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, 
 /* average device duration of the fused step kernel over the launches made while the kernel timer was armed */
 int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
 int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
-int dql_use_graph(dql_ctx* ctx, int32_t enable);
 /* tuning knobs: "lds_tables" (0/1: stage the Q tables in LDS), "block" (0 = auto, 64, 128, 256 threads per workgroup) */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 

@@ -389,7 +389,9 @@ static void bwc_init(bwc_t* b, double c) {
 }
 /* pkg/filters.py:98-109; history x1,x2 = previous two inputs, y1..y3 = previous three outputs (the deque keeps 3) */
 static inline REAL butterworth(const bwc_t* b, REAL x0, REAL* x1, REAL* x2, REAL* y1, REAL* y2, REAL* y3) {
-  const REAL value = b->inv_denom * (*x2 + R_(2.0) * *x1 + x0 - b->k1 * *y3 - (b->k2 * *y2));
+  REAL acc = *x2 + R_(2.0) * *x1 + x0 - b->k1 * *y3;
+  if (b->k2 != R_(0.0)) acc = acc - (b->k2 * *y2); /* -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106) */
+  const REAL value = b->inv_denom * acc;
   *x2 = *x1; *x1 = x0;
   *y3 = *y2; *y2 = *y1; *y1 = value;
   return value;
@@ -412,7 +414,7 @@ static inline REAL pid_output(const pidc_t* c, const bwc_t* b, pid_t_* s, REAL d
 /* pkg/filters.py:19-36 */
 static inline REAL kalman1d(REAL* x, REAL* P, REAL Q, REAL Rm, REAL z) {
   *P += Q;
-  const REAL K = *P / (*P + Rm);
+  const REAL K = (Rm == R_(0.0)) ? R_(1.0) : *P / (*P + Rm); /* P / (P + 0) is exactly 1 */
   *x += K * (z - *x);
   *P *= (R_(1.0) - K);
   return *x;
@@ -422,7 +424,7 @@ static inline REAL kalman1d(REAL* x, REAL* P, REAL Q, REAL Rm, REAL z) {
  * simulator constants
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-  REAL dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, aup, adn, omax, cd, crd;
+  REAL dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   REAL kR[3], kW[3], ia, ib, ic; /* inverse allocation coefficients */
   pidc_t pvz, pyaw; bwc_t bw;
   REAL mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma, p_max;
@@ -436,6 +438,7 @@ static void simc_init(simc_t* s, const dql_config* c) {
   s->dt = (REAL)c->dt; s->g = (REAL)c->gravity; s->inv_m = (REAL)(1.0 / c->mass);
   for (int i = 0; i < 3; ++i) { s->I[i] = (REAL)c->inertia[i]; s->inv_I[i] = (REAL)(1.0 / c->inertia[i]); s->kR[i] = (REAL)c->k_R[i]; s->kW[i] = (REAL)c->k_W[i]; }
   s->l = (REAL)c->arm_length; s->h = (REAL)c->rotor_z; s->kf = (REAL)c->k_f; s->km = (REAL)c->k_m;
+  s->lkf = (REAL)(c->arm_length * c->k_f); s->kmkf = (REAL)(c->k_m * c->k_f);
   s->aup = (REAL)c->rotor_alpha_up; s->adn = (REAL)c->rotor_alpha_down; s->omax = (REAL)c->rotor_max;
   s->cd = (REAL)c->c_drag; s->crd = (REAL)(c->c_roll / c->c_drag);
   /* closed-form inverse of the allocation matrix of pkg/attitude_controller.py:94-104 ("plus" layout) */
@@ -497,17 +500,21 @@ static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], c
 /* gazebo_motor_model.cpp:434-500 (forces from the CURRENT rotor speeds) + one semi-implicit Euler step of the body */
 static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], const REAL cmd[4]) {
   const REAL* om = e->om; const REAL* w = e->w; const REAL l = s->l, h = s->h;
-  const REAL T0 = s->kf * om[0] * om[0], T1 = s->kf * om[1] * om[1], T2 = s->kf * om[2] * om[2], T3 = s->kf * om[3] * om[3];
+  /* thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
+   * (gazebo_motor_model.cpp:441-452, 476-482; allocation signs pkg/attitude_controller.py:98-104) */
+  const REAL q0 = om[0] * om[0], q1 = om[1] * om[1], q2 = om[2] * om[2], q3 = om[3] * om[3];
+  const REAL Fbz = s->kf * ((q0 + q1) + (q2 + q3));
+  REAL tx = s->lkf * (q1 - q3), ty = s->lkf * (q2 - q0), tz = s->kmkf * ((q0 - q1) + (q2 - q3));
+  /* rotor drag -|om_i| c_d v_perp,i (gazebo_motor_model.cpp:458-469), v_perp,i = (v_body + w x r_i) in the rotor plane,
+   * summed over the four rotors in closed form; rolling moment (:484-489) = (c_r / c_d) x the drag force */
   const REAL vbx = FMA(R[0], e->v[0], FMA(R[3], e->v[1], R[6] * e->v[2]));
   const REAL vby = FMA(R[1], e->v[0], FMA(R[4], e->v[1], R[7] * e->v[2]));
   const REAL uxc = FMA(w[1], h, vbx), uyc = FMA(-w[0], h, vby), wzl = w[2] * l;
-  const REAL ux[4] = {uxc, uxc - wzl, uxc, uxc + wzl};
-  const REAL uy[4] = {uyc + wzl, uyc, uyc - wzl, uyc};
-  REAL dx[4], dy[4];
-  for (int i = 0; i < 4; ++i) { const REAL k = -(s->cd * om[i]); dx[i] = k * ux[i]; dy[i] = k * uy[i]; }
-  const REAL Fbx = (dx[0] + dx[1]) + (dx[2] + dx[3]), Fby = (dy[0] + dy[1]) + (dy[2] + dy[3]), Fbz = (T0 + T1) + (T2 + T3);
-  REAL tx = l * (T1 - T3), ty = l * (T2 - T0), tz = s->km * ((T0 - T1) + (T2 - T3));
-  tx = FMA(-h, Fby, tx); ty = FMA(h, Fbx, ty); tz = FMA(l, (dy[0] - dy[2]) - (dx[1] - dx[3]), tz);
+  const REAL S = (om[0] + om[1]) + (om[2] + om[3]), d02 = om[0] - om[2], d13 = om[1] - om[3];
+  const REAL Fbx = -(s->cd * FMA(S, uxc, -(wzl * d13)));
+  const REAL Fby = -(s->cd * FMA(S, uyc, wzl * d02));
+  const REAL tzd = -(s->cd * FMA(uyc, d02, FMA(wzl, S, -(uxc * d13))));
+  tx = FMA(-h, Fby, tx); ty = FMA(h, Fbx, ty); tz = FMA(l, tzd, tz);
   tx = FMA(s->crd, Fbx, tx); ty = FMA(s->crd, Fby, ty);
   /* rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364) */
   for (int i = 0; i < 4; ++i) {
