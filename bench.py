@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the multi-rank path on fewer GPUs (host-side exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +157,15 @@ def main():
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
         }
+        if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
+            # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
+            big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis), args.large_envs, seed=42)
+            big.train_steps(20, args.eps); big.sync()
+            b0 = big.stats(); big.timer_start(); big.train_steps(150, args.eps); b_ms = big.timer_stop(); b1 = big.stats()
+            b_dec = b1["decisions"] - b0["decisions"]
+            out["large_batch"] = {"envs": args.large_envs, "value": b_dec / (b_ms * 1e-3), "unit": "env-steps/s", "ms_per_step": b_ms / 150,
+                                  "hbm_frac_algorithmic": algo_b * b_dec / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            big.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
         print(json.dumps(out), flush=True)

@@ -187,9 +187,9 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
 }
 
 // mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)), count += m
-DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
+DQL_DEV double contract_value(double q, double cnt, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
   const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
-  const long long c0 = (long long)count[cell];
+  const long long c0 = (long long)cnt;
   double shrink = 1.0;
   long long j = 0;
   const long long m_eff = per_step ? 1 : m;
@@ -200,7 +200,10 @@ DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, 
     while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; }
     shrink *= pw;
   }
-  qa[cell] = tbar + (qa[cell] - tbar) * shrink;
+  return tbar + (q - tbar) * shrink;
+}
+DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
+  qa[cell] = contract_value(qa[cell], count[cell], Tsum, m, alpha_tab, n_tab, alpha_min, per_step);
   count[cell] += (double)m;
 }
 
@@ -215,11 +218,14 @@ struct PostArgs {
 __global__ void k_post(PostArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < DQL_N_CELLS) {
+    // all four loads are issued together (one memory latency instead of a dependent chain)
     const long long Tsum = a.accum[c], m = a.accum[DQL_N_CELLS + c];
+    const double q = a.qa[c], cnt = a.count[c];
     if (m > 0) {
       if (a.learn) {
         if (a.windowed) { a.window[c] += Tsum; a.window[DQL_N_CELLS + c] += m; }
-        contract_cell(a.qa, a.count, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
+        a.qa[c] = contract_value(q, cnt, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
+        a.count[c] = cnt + (double)m;
       }
       a.accum[c] = 0; a.accum[DQL_N_CELLS + c] = 0;
     }
@@ -383,7 +389,7 @@ template <typename T, int BLOCK, bool LDS_TAB> static void launch_step_t(dql_ctx
 }
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
   int block = x->block;
-  if (block == 0) block = (x->n <= 32768) ? 64 : 256;  // small batches: one wave per workgroup spreads over more CUs
+  if (block == 0) block = (x->n <= 4096) ? 64 : 256;  // measured (profiles/r1_sweep_blocks.jsonl): 256 wins from 8192 envs up
   if (x->lds_tables) {
     if (block == 64) launch_step_t<T, 64, true>(x, mode, eps); else if (block == 128) launch_step_t<T, 128, true>(x, mode, eps); else launch_step_t<T, 256, true>(x, mode, eps);
   } else {
