@@ -125,3 +125,46 @@ def test_greedy_evaluation_of_reference_tables(golden_dir):
     import simulation
     h = simulation.evaluate(golden_dir / "assets", n_envs=512, level=4, max_steps=520)
     assert sum(h.values()) == 512 and h["unfinished"] == 0
+
+
+def test_error_behaviour_matches_reference_exception_types():
+    """SURVEY.md section 8b error convention: the same exception types for the same conditions."""
+    from dql_multirotor_landing_amd import ops
+    from dql_multirotor_landing_amd.config import DqlConfig, F64
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    from dql_multirotor_landing_amd.engine import Engine
+    from dql_multirotor_landing_amd.mdp import ContinuousObservation, Observation, TrainingMdp
+    cfg = DqlConfig(dtype=F64)
+    # the reference raises ValueError("Unexpected discretization case") for values it cannot bin (NaN here) (pkg/mdp.py:170)
+    assert ops.discretise(cfg, [np.nan], [0.0], [0.0], [0.0])[0] == -1
+    m = TrainingMdp(0, 22.92, 20, 4.5)
+    m.reset()
+    with pytest.raises(ValueError):
+        m.discrete_state(ContinuousObservation(Observation(rel_p_x=float("nan"))))
+    # empty / ragged inputs
+    assert len(ops.discretise(cfg, [], [], [], [])) == 0
+    with pytest.raises(ValueError):
+        ops.discretise(cfg, [0.0, 1.0], [0.0], [0.0], [0.0])
+    with pytest.raises(ValueError):
+        ops.agent_predict(np.zeros(2835), np.zeros(2835), [945])  # state index out of range
+    with pytest.raises(ValueError):
+        Engine(DqlConfig(working_curriculum_step=5), 8)
+    with pytest.raises(ValueError):
+        Engine(DqlConfig(pid_vz=[5.0, 10.0, 1.0, 0.0, 10.0, 10.0]), 8)  # Kd != 0 is outside the fused kernel
+    with pytest.raises(ValueError):
+        Engine(cfg, 0)
+    e = Engine(cfg, 8)
+    with pytest.raises(ValueError):
+        e.set_tables(np.zeros(10))
+    with pytest.raises(ValueError):
+        e.step(np.zeros(7, dtype=np.uint8))  # ragged action vector
+    with pytest.raises(ValueError):
+        e.set_curriculum(5)
+    with pytest.raises(ValueError):
+        e.apply_accum()  # needs windowed accumulation
+    e.close()
+    a = DoubleQLearningAgent(5)
+    with pytest.raises(IndexError):
+        a.predict((0, 3, 0, 0, 0))
+    with pytest.raises(IndexError):
+        a.update((0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0), 0.1, 0.99, 1.0)
