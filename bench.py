@@ -29,18 +29,34 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 
 
 def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
-    """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on ONE host core, bounded sample."""
+    """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on the host cores, bounded sample:
+    all cores (OpenMP over envs) as the headline value, one thread next to it."""
     from dql_multirotor_landing_amd.config import DqlConfig
     from oracle.oracle import Oracle
-    o = Oracle(DqlConfig(dtype=dtype, two_axis=two_axis), envs, seed=42)
-    o.train_steps(3, 1.0)
-    d0 = o.stats_dict()["decisions"]
-    t0 = time.perf_counter()
-    o.train_steps(steps, 1.0)
-    dt = time.perf_counter() - t0
-    d = o.stats_dict()["decisions"] - d0
-    return {"value": d / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{envs} envs x {steps} agent periods ({d} env-steps, {dt:.1f} s), single thread, same dtype, gcc -O2"}
+
+    def run(threads, n_steps):
+        o = Oracle(DqlConfig(dtype=dtype, two_axis=two_axis), envs, seed=42, n_threads=threads)
+        o.train_steps(3, 1.0)
+        d0 = o.stats_dict()["decisions"]
+        t0 = time.perf_counter()
+        o.train_steps(n_steps, 1.0)
+        dt = time.perf_counter() - t0
+        return (o.stats_dict()["decisions"] - d0), dt
+
+    # usable host cores: affinity mask, capped by the cgroup CPU quota (a GPU box exposes every core of the host but grants a share)
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 16))
+    d1, t1 = run(1, steps)
+    dn, tn = run(cores, steps * min(cores, 16))
+    return {"value": dn / tn, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{envs} envs x {steps * min(cores, 16)} agent periods ({dn} env-steps, {tn:.1f} s), OpenMP over envs on {cores} threads, same dtype, gcc -O2 -fopenmp",
+            "single_thread_value": d1 / t1, "single_thread_sample": f"{envs} envs x {steps} agent periods ({d1} env-steps, {t1:.1f} s)"}
 
 
 def main():
@@ -55,9 +71,11 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--lds-tables", type=int, default=0)
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
+    ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
+    ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the multi-rank path on fewer GPUs (host-side exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     args = ap.parse_args()
 
@@ -87,7 +105,8 @@ def main():
         torch.cuda.set_device(dev_index)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis)
+    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis, per_env_platform=args.randomize_platform,
+                    noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index if world > 1 else 0, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
     eng.set_option("lds_tables", args.lds_tables)
@@ -149,7 +168,8 @@ def main():
             "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
                                    f"rpm platform r=2 m omega=0.8 rad/s, fused step kernel + int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
-                       "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables},
+                       "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables,
+                       "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,

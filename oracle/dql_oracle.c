@@ -774,19 +774,31 @@ EXPORT void ORC(init_envs)(const dql_config* c, void* envs_, int64_t n, uint64_t
   }
 }
 
+/* n_threads > 1: envs are split over OpenMP threads (cpu_baseline leg of bench.py); every thread adds into its own
+ * accumulators, merged with integer sums, so the result does not depend on the thread count */
 EXPORT void ORC(agent_periods)(const dql_config* c, void* envs_, int64_t n, const double* qa, const double* qb, int64_t* accum,
                                int64_t* stats_out /* [2 + 9 + 1] */, int mode, double eps, const uint8_t* ext_actions, uint64_t seed,
-                               int64_t env_id_offset, int64_t step_index, int64_t g0, int n_ticks) {
+                               int64_t env_id_offset, int64_t step_index, int64_t g0, int n_ticks, int n_threads) {
   env_t* envs = (env_t*)envs_;
   simc_t s; simc_init(&s, c);
   mdpc_t m; mdpc_init(&m, c);
-  ostats_t st; memset(&st, 0, sizeof(st));
-  for (int64_t i = 0; i < n; ++i)
-    env_agent_period(&s, &m, &envs[i], qa, qb, accum, &st, mode, eps, ext_actions ? ext_actions + i : 0, seed,
-                     (uint32_t)(env_id_offset + i), step_index, g0, n_ticks, c->gamma);
-  stats_out[0] += st.decisions; stats_out[1] += st.episodes;
-  for (int k = 0; k < DQL_N_CHECK_CODES; ++k) stats_out[2 + k] += st.by_code[k];
-  stats_out[11] += st.reward_fx;
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads) if (n_threads > 1)
+  {
+    ostats_t st; memset(&st, 0, sizeof(st));
+    int64_t* acc = n_threads > 1 ? (int64_t*)calloc(2 * DQL_N_CELLS, sizeof(int64_t)) : accum;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+      env_agent_period(&s, &m, &envs[i], qa, qb, acc, &st, mode, eps, ext_actions ? ext_actions + i : 0, seed,
+                       (uint32_t)(env_id_offset + i), step_index, g0, n_ticks, c->gamma);
+#pragma omp critical
+    {
+      if (n_threads > 1) { for (int k = 0; k < 2 * DQL_N_CELLS; ++k) accum[k] += acc[k]; free(acc); }
+      stats_out[0] += st.decisions; stats_out[1] += st.episodes;
+      for (int k = 0; k < DQL_N_CHECK_CODES; ++k) stats_out[2 + k] += st.by_code[k];
+      stats_out[11] += st.reward_fx;
+    }
+  }
 }
 
 EXPORT void ORC(get_fields)(const void* envs_, int64_t n, double* reals /*[NF_REAL][n]*/, int32_t* ints /*[NF_INT][n]*/) {

@@ -51,7 +51,7 @@ def _f64(a):
 class Oracle:
     """N environments + tables stepped on the CPU with the batched semantics the HIP product implements."""
 
-    def __init__(self, cfg: DqlConfig, n_envs: int, seed: int = 42, env_id_offset: int = 0, alpha_tab=None):
+    def __init__(self, cfg: DqlConfig, n_envs: int, seed: int = 42, env_id_offset: int = 0, alpha_tab=None, n_threads: int = 1):
         self.cfg = cfg
         self.c = cfg.to_c()
         self.n = int(n_envs)
@@ -69,6 +69,7 @@ class Oracle:
         self.alpha_tab = cfg.alpha_table() if alpha_tab is None else _f64(alpha_tab)
         self.step_index = 0
         self.windowed = False
+        self.n_threads = int(n_threads)
         getattr(L, self.pfx + "init_envs")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), C.c_uint64(self.seed), C.c_int64(self.off))
 
     def _fn(self, name):
@@ -110,7 +111,7 @@ class Oracle:
         act = None if actions is None else np.ascontiguousarray(actions, dtype=np.uint8)
         self._fn("agent_periods")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), _p(self.qa), _p(self.qb), _p(self.accum),
                                    _p(self.stats), C.c_int(mode), C.c_double(eps), _p(act) if act is not None else None,
-                                   C.c_uint64(self.seed), C.c_int64(self.off), C.c_int64(j), C.c_int64(g0), C.c_int(n_ticks))
+                                   C.c_uint64(self.seed), C.c_int64(self.off), C.c_int64(j), C.c_int64(g0), C.c_int(n_ticks), C.c_int(self.n_threads))
         self.step_index += 1
 
     def _contract(self, qa, count, accum):

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[0]: ONE env, x-axis, curriculum step 0, 1 000 time steps through the drop-in single-env API
+(`TrainingLandingEnv.reset/.step`, `DoubleQLearningAgent.guess/.update`, `Trainer.alpha/.exploration_rate`) exactly as the
+reference's trainer loop drives them (pkg/trainer.py:187-212) — plumbing: Python host -> ctypes -> HIP kernels -> .npy round trip.
+The reference + Gazebo needs 1/22.92 s of wall time per step (>= 43.6 s for these 1 000 steps); it cannot run here."""
+import json
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+if __name__ == "__main__":
+    import __graft_entry__ as g
+    g.build_hip()
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    from dql_multirotor_landing_amd.landing_simulation_env import TrainingLandingEnv
+    from dql_multirotor_landing_amd.trainer import Trainer
+    with tempfile.TemporaryDirectory() as d:
+        tr = Trainer(save_path=Path(d) / "run", n_envs=1)  # np.random.seed(42) as the reference's Trainer does
+        agent = tr._double_q_learning_agent
+        env = TrainingLandingEnv(0, t_max=20, f_ag=22.92, p_max=4.5, z_init=4.0)
+        steps, episodes = 0, 0
+        t0 = time.perf_counter()
+        while steps < 1000:
+            s = env.reset(); done = False
+            while not done and steps < 1000:
+                a = agent.guess(s, tr.exploration_rate(episodes, 0))
+                s2, r, done, info = env.step(a)
+                sa = s + (a,)
+                agent.update(sa, s2, tr.alpha(sa), 0.99, r)
+                s = s2; steps += 1
+            episodes += 1
+        wall = time.perf_counter() - t0
+        agent.save(Path(d))
+        back = DoubleQLearningAgent.load(Path(d))
+        ok = np.array_equal(back.Q_table_a, agent.Q_table_a) and np.array_equal(back.state_action_counter, agent.state_action_counter)
+    print(json.dumps({"config": "BASELINE configs[0]: 1 env, x-axis, level 0, 1000 steps, single-env drop-in API on the GPU",
+                      "steps": steps, "episodes": episodes, "wall_s": wall, "env_steps_per_s": steps / wall,
+                      "visits": float(agent.state_action_counter.sum()), "npy_round_trip_ok": bool(ok),
+                      "reference_gazebo_env_steps_per_s": 20.18}))
