@@ -17,3 +17,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_artefacts_built():
+    """Build (or reuse) the HIP library and the CPU oracle before any test: a fresh checkout has neither."""
+    import __graft_entry__ as g
+    g.build()
