@@ -69,7 +69,6 @@ def main():
     ap.add_argument("--eps", type=float, default=1.0)
     ap.add_argument("--sync-period", type=int, default=32)
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--lds-tables", type=int, default=0)
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
@@ -109,7 +108,6 @@ def main():
                     noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index if world > 1 else 0, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
-    eng.set_option("lds_tables", args.lds_tables)
     reducer = None
     if world > 1:
         reducer = TorchWindowReducer(eng, dev_index) if args.backend == "nccl" else HostWindowReducer(eng)
@@ -166,9 +164,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
-                                   f"rpm platform r=2 m omega=0.8 rad/s, fused step kernel + int64 LDS/global accumulators",
+                                   f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per agent period (env step + table fold in writer workgroups), int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
-                       "parallelism": f"env-shard x{world}", "block": args.block, "lds_tables": args.lds_tables,
+                       "parallelism": f"env-shard x{world}", "block": args.block,
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,

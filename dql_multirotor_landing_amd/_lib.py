@@ -57,6 +57,7 @@ SYMBOLS = {
     "dql_accum_dev_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "dql_set_window_buffer": (C.c_int, [_vp, _vp]),
     "dql_stream_handle": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dql_flush": (C.c_int, [_vp]),
     "dql_apply_accum": (C.c_int, [_vp]),
     "dql_get_accum": (C.c_int, [_vp, _vp]),
     "dql_set_accum": (C.c_int, [_vp, _vp]),

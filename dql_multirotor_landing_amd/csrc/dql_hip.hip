@@ -1,12 +1,15 @@
 // dql_hip.hip — kernels + C ABI (include/dql.h) of the MI355X UAV-landing / tabular Double-Q hot path.
 //
 // Kernels (all wave64, gfx950):
-//   k_step<T,BLOCK,LDS_TAB>  fused agent period: eps-greedy guess, 21/22 physics ticks (PID, SO(3) attitude law, rotor
+//   k_step<T,BLOCK>          fused agent period: eps-greedy guess, 21/22 physics ticks (PID, SO(3) attitude law, rotor
 //                            model, rigid body, platform, 100 Hz observation pipeline), discretise/check/reward, TD target.
 //                            One lane per env, state in VGPRs, 16-byte coalesced quad loads/stores, per-workgroup LDS
 //                            accumulators (int64 fixed-point target sums + visit counts), wave64 shuffle reductions of the
 //                            counters, one global atomic per touched cell per workgroup.
-//   k_post                   folds the accumulators into the tables (mean-target contraction), advances the tick schedule.
+//                            Extra "table-writer" workgroups of the same launch fold the PREVIOUS launch's accumulators into
+//                            the master tables (mean-target contraction) and publish the acting tables of the NEXT launch, so
+//                            the table update has no kernel and no time of its own (tables act with one period of delay).
+//   k_flush                  same fold outside a launch (host table access, level switch, rank sync).
 //   k_apply_window           multi-GPU: folds the all-reduced window accumulators into the base tables.
 //   small stateless kernels  drop-in single-call operators (discretise, mdp transition, predict, ordered update).
 #include <hip/hip_runtime.h>
@@ -34,7 +37,6 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 #define CHECK_CTX(ctx) do { if (!(ctx)) return fail(DQL_EINVAL, "null context"); } while (0)
 
-struct Sched { long long step_index, g0; int n_ticks, pad; };
 struct StatsDev { unsigned long long decisions, episodes, by_code[DQL_N_CHECK_CODES]; long long reward_fx; unsigned long long agent_steps; };
 
 // ---------------------------------------------------------------------------------------------
@@ -113,19 +115,53 @@ template <typename T> __global__ void k_init(InitArgs<T> a) {
   store_env(e, a.sr, a.si, n, i, s);
 }
 
+// mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j))
+struct FoldK { const double* alpha_tab; int n_tab; double alpha_min; int per_step; };
+DQL_DEV double fold_q(const FoldK& f, double q, double cnt, long long Tsum, long long m) {
+  const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
+  const long long c0 = (long long)cnt;
+  double shrink = 1.0;
+  long long j = 0;
+  const long long m_eff = f.per_step ? 1 : m;
+  for (; j < m_eff && c0 + j < f.n_tab; ++j) shrink *= (1.0 - f.alpha_tab[c0 + j]);
+  long long rem = m_eff - j;
+  if (rem > 0) {
+    double base = 1.0 - f.alpha_min, pw = 1.0;
+    while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; }
+    shrink *= pw;
+  }
+  return tbar + (q - tbar) * shrink;
+}
+// fold one cell of an accumulator pair into the master tables (and the multi-GPU window), clear the accumulator
+DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long* acc, long long* window, int windowed, int c) {
+  const long long Tsum = acc[c], m = acc[DQL_N_CELLS + c];
+  double q = qa_m[c];
+  if (m > 0) {
+    const double cnt = cnt_m[c];
+    if (windowed) { window[c] += Tsum; window[DQL_N_CELLS + c] += m; }
+    q = fold_q(f, q, cnt, Tsum, m);
+    qa_m[c] = q; cnt_m[c] = cnt + (double)m;
+    acc[c] = 0; acc[DQL_N_CELLS + c] = 0;
+  }
+  return q;
+}
+
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T>* mdp;
   Quad<T>* sr; int4* si;
-  const double* qa; const double* qb;
-  unsigned long long* accum;  // [2][DQL_N_CELLS]: target sums (fixed point), visits
+  const double* qa; const double* qb;  // ACTING tables of this launch: every accumulator up to launch j-2 folded in
+  unsigned long long* acc_cur;         // [2][DQL_N_CELLS] of this launch: target sums (fixed point), visits
+  // table-writer blocks (blockIdx >= env_blocks): fold launch j-1's accumulators into the master tables while the env blocks
+  // run, publish the result as the acting tables of launch j+1 -> the table update costs no kernel and no time of its own
+  double* qa_m; double* cnt_m; double* qa_pub; long long* acc_prev; long long* window;
+  FoldK fold;
   StatsDev* stats;
-  const Sched* sched;
   const uint8_t* actions;
-  long long n, env_id_offset;
+  long long n, env_id_offset, step_index, g0;
   unsigned long long seed;
   double eps;
-  int mode;
+  int mode, n_ticks, env_blocks, have_prev, windowed;
 };
 
 DQL_DEV long long wave_sum(long long v) {
@@ -137,30 +173,31 @@ DQL_DEV long long wave_sum(long long v) {
 #ifndef DQL_WAVES_PER_EU
 #define DQL_WAVES_PER_EU 1
 #endif
-template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
+template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
   __shared__ unsigned long long sT[DQL_N_CELLS];
   __shared__ unsigned int sM[DQL_N_CELLS];
   __shared__ unsigned long long sStat[4];
-  __shared__ double sQ[LDS_TAB ? 2 * DQL_N_CELLS : 1];
   const int tid = threadIdx.x;
-  const int ncell = (a.c.working + 1) * DQL_CELLS_PER_LEVEL;
-  for (int c = tid; c < ncell; c += BLOCK) {
-    sT[c] = 0ull; sM[c] = 0u;
-    if (LDS_TAB) { sQ[c] = a.qa[c]; sQ[DQL_N_CELLS + c] = a.qb[c]; }
+  if ((int)blockIdx.x >= a.env_blocks) {  // table-writer block (whole block takes this path: no barrier is skipped)
+    const int c = ((int)blockIdx.x - a.env_blocks) * BLOCK + tid;
+    if (c < DQL_N_CELLS) {
+      double q = a.qa_m[c];
+      if (a.have_prev) q = fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc_prev, a.window, a.windowed, c);
+      a.qa_pub[c] = q;
+    }
+    return;
   }
+  const int ncell = (a.c.working + 1) * DQL_CELLS_PER_LEVEL;
+  for (int c = tid; c < ncell; c += BLOCK) { sT[c] = 0ull; sM[c] = 0u; }
   if (tid < 4) sStat[tid] = 0ull;
   __syncthreads();
-  const long long step_index = a.sched->step_index, g0 = a.sched->g0;
-  const int n_ticks = a.sched->n_ticks;
   const long long i = (long long)blockIdx.x * BLOCK + tid;
   long long dec = 0, don = 0, rfx = 0;
   if (i < a.n) {
     Env<T> e;
     load_env(e, a.sr, a.si, a.n, i, a.c);
     const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-    StepOut o;
-    if (LDS_TAB) o = agent_period(a.c, a.mdp, e, (const double*)sQ, (const double*)(sQ + DQL_N_CELLS), a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
-    else o = agent_period(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), step_index, g0, n_ticks);
+    const StepOut o = agent_period(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
     store_env(e, a.sr, a.si, a.n, i, a.c);
     if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
     if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
@@ -177,7 +214,7 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
   __syncthreads();
   for (int c = tid; c < ncell; c += BLOCK) {
     const unsigned int m = sM[c];
-    if (m) { atomicAdd(&a.accum[c], sT[c]); atomicAdd(&a.accum[DQL_N_CELLS + c], (unsigned long long)m); }
+    if (m) { atomicAdd(&a.acc_cur[c], sT[c]); atomicAdd(&a.acc_cur[DQL_N_CELLS + c], (unsigned long long)m); }
   }
   if (tid == 0) {
     if (sStat[0]) atomicAdd(&a.stats->decisions, sStat[0]);
@@ -186,67 +223,25 @@ template <typename T, int BLOCK, bool LDS_TAB> __global__ __launch_bounds__(BLOC
   }
 }
 
-// mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)), count += m
-DQL_DEV double contract_value(double q, double cnt, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
-  const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
-  const long long c0 = (long long)cnt;
-  double shrink = 1.0;
-  long long j = 0;
-  const long long m_eff = per_step ? 1 : m;
-  for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
-  long long rem = m_eff - j;
-  if (rem > 0) {
-    double base = 1.0 - alpha_min, pw = 1.0;
-    while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; }
-    shrink *= pw;
-  }
-  return tbar + (q - tbar) * shrink;
-}
-DQL_DEV void contract_cell(double* qa, double* count, int cell, long long Tsum, long long m, const double* alpha_tab, int n_tab, double alpha_min, int per_step) {
-  qa[cell] = contract_value(qa[cell], count[cell], Tsum, m, alpha_tab, n_tab, alpha_min, per_step);
-  count[cell] += (double)m;
-}
-
-struct PostArgs {
-  double* qa; double* count;         // work tables (the ones the step kernel reads)
-  long long* accum;                  // per-step accumulators, cleared here
-  long long* window;                 // multi-GPU window accumulators (windowed != 0)
-  const double* alpha_tab; int n_tab; double alpha_min;
-  Sched* sched; StatsDev* stats; double tick_ratio;  // 1 / (f_ag * dt)
-  int learn, windowed, per_step;
-};
-__global__ void k_post(PostArgs a) {
+// fold the last launch's accumulators into the master tables outside a launch (host table access, level switch, rank sync)
+struct FlushArgs { double* qa_m; double* cnt_m; long long* acc; long long* window; FoldK fold; int windowed; };
+__global__ void k_flush(FlushArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < DQL_N_CELLS) {
-    // all four loads are issued together (one memory latency instead of a dependent chain)
-    const long long Tsum = a.accum[c], m = a.accum[DQL_N_CELLS + c];
-    const double q = a.qa[c], cnt = a.count[c];
-    if (m > 0) {
-      if (a.learn) {
-        if (a.windowed) { a.window[c] += Tsum; a.window[DQL_N_CELLS + c] += m; }
-        a.qa[c] = contract_value(q, cnt, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
-        a.count[c] = cnt + (double)m;
-      }
-      a.accum[c] = 0; a.accum[DQL_N_CELLS + c] = 0;
-    }
-  }
-  if (c == 0) {
-    const long long j = a.sched->step_index + 1;
-    const long long t0 = (long long)floor((double)j * a.tick_ratio), t1 = (long long)floor((double)(j + 1) * a.tick_ratio);
-    a.sched->step_index = j; a.sched->g0 = t0; a.sched->n_ticks = (int)(t1 - t0);
-    a.stats->agent_steps += 1;
-  }
+  if (c < DQL_N_CELLS) fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc, a.window, a.windowed, c);
 }
-struct WindowArgs { double* qa_base; double* count_base; double* qa_work; double* count_work; long long* window; const double* alpha_tab; int n_tab; double alpha_min; int per_step; };
+// multi-GPU: fold the all-reduced window into the base tables; master and both acting buffers restart from the base
+struct WindowArgs { double* qa_base; double* count_base; double* qa_m; double* cnt_m; double* tb0; double* tb1; long long* window; FoldK fold; };
 __global__ void k_apply_window(WindowArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= DQL_N_CELLS) return;
   const long long Tsum = a.window[c], m = a.window[DQL_N_CELLS + c];
   if (m > 0) {
-    contract_cell(a.qa_base, a.count_base, c, Tsum, m, a.alpha_tab, a.n_tab, a.alpha_min, a.per_step);
+    a.qa_base[c] = fold_q(a.fold, a.qa_base[c], a.count_base[c], Tsum, m);
+    a.count_base[c] += (double)m;
     a.window[c] = 0; a.window[DQL_N_CELLS + c] = 0;
   }
-  a.qa_work[c] = a.qa_base[c]; a.count_work[c] = a.count_base[c];
+  const double q = a.qa_base[c];
+  a.qa_m[c] = q; a.cnt_m[c] = a.count_base[c]; a.tb0[c] = q; a.tb1[c] = q;
 }
 __global__ void k_mark_reset(int4* si, const uint8_t* mask, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,11 +317,16 @@ struct dql_ctx {
   size_t real_size = 4;
   void* sr = nullptr;  // Quad<T>[NQ_REAL][n]
   int4* si = nullptr;
-  double *qa = nullptr, *qb = nullptr, *count = nullptr;          // work tables
+  double *qa = nullptr, *qb = nullptr, *count = nullptr;          // MASTER tables: every accumulator folded except the last launch's (`pending`)
+  double* tb[2] = {nullptr, nullptr};                             // ACTING copies of Q_table_a: launch j reads tb[j & 1], its writer blocks fill tb[(j + 1) & 1]
   double *qa_base = nullptr, *count_base = nullptr;               // multi-GPU base tables
-  long long *accum = nullptr, *window = nullptr, *window_own = nullptr;
+  long long* acc[2] = {nullptr, nullptr};                         // accumulators: launch j adds into acc[j & 1]; its writer blocks fold and clear acc[(j + 1) & 1]
+  long long *window = nullptr, *window_own = nullptr;
   double* alpha_tab = nullptr; int n_tab = 0;
-  Sched* sched = nullptr; StatsDev* stats = nullptr;
+  StatsDev* stats = nullptr;
+  long long step_index = 0;      // agent periods launched so far (the tick schedule is a pure function of it)
+  long long stats_step_base = 0;
+  bool pending = false;          // acc[(step_index + 1) & 1] holds the last launch's accumulators, not yet folded into the master tables
   uint8_t* d_actions = nullptr;
   void* mdpk = nullptr;  // MdpK<T> in device memory
   hipStream_t stream = nullptr;
@@ -336,7 +336,6 @@ struct dql_ctx {
   long long timer_launches = 0;
   int sync_period = 1;
   bool windowed = false;
-  int lds_tables = 0;
   int block = 0;  // 0 = auto
 };
 
@@ -370,32 +369,30 @@ template <typename T> static int launch_init(dql_ctx* x) {
   return DQL_OK;
 }
 
-static int host_sched_init(dql_ctx* x) {
-  const double ratio = 1.0 / (x->cfg.f_ag * x->cfg.dt);
-  Sched s;
-  s.step_index = 0; s.g0 = 0; s.n_ticks = (int)((long long)std::floor(1.0 * ratio) - 0); s.pad = 0;
-  HIP_TRY(hipMemcpyAsync(x->sched, &s, sizeof(s), hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
-  return DQL_OK;
-}
+static FoldK make_foldk(const dql_ctx* x) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step}; }
+static long long ticks_before(const dql_ctx* x, long long j) { return (long long)std::floor((double)j * (1.0 / (x->cfg.f_ag * x->cfg.dt))); }
 
-template <typename T, int BLOCK, bool LDS_TAB> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+template <typename T, int BLOCK> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+  const long long j = x->step_index;
   StepArgs<T> a;
   a.c = make_simk<T>(x->cfg);
   a.mdp = (const MdpK<T>*)x->mdpk;
-  a.sr = (Quad<T>*)x->sr; a.si = x->si; a.qa = x->qa; a.qb = x->qb; a.accum = (unsigned long long*)x->accum; a.stats = x->stats;
-  a.sched = x->sched; a.actions = x->d_actions; a.n = x->n; a.env_id_offset = x->env_id_offset; a.seed = x->seed; a.eps = eps; a.mode = mode;
-  hipLaunchKernelGGL((k_step<T, BLOCK, LDS_TAB>), dim3((unsigned)((x->n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, x->stream, a);
+  a.sr = (Quad<T>*)x->sr; a.si = x->si;
+  a.qa = x->tb[j & 1]; a.qb = x->qb; a.acc_cur = (unsigned long long*)x->acc[j & 1];
+  a.qa_m = x->qa; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
+  a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->d_actions;
+  a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
+  a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_ticks = (int)(ticks_before(x, j + 1) - a.g0);
+  a.env_blocks = (int)((x->n + BLOCK - 1) / BLOCK); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
+  const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL((k_step<T, BLOCK>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
   int block = x->block;
   if (block == 0) block = (x->n <= 4096) ? 64 : 256;  // measured (profiles/r1_sweep_blocks.jsonl): 256 wins from 8192 envs up
-  if (x->lds_tables) {
-    if (block == 64) launch_step_t<T, 64, true>(x, mode, eps); else if (block == 128) launch_step_t<T, 128, true>(x, mode, eps); else launch_step_t<T, 256, true>(x, mode, eps);
-  } else {
-    if (block == 64) launch_step_t<T, 64, false>(x, mode, eps); else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps); else launch_step_t<T, 256, false>(x, mode, eps);
-  }
+  if (block == 64) launch_step_t<T, 64>(x, mode, eps); else if (block == 128) launch_step_t<T, 128>(x, mode, eps); else launch_step_t<T, 256>(x, mode, eps);
 }
+// ONE kernel per agent period
 static int launch_period(dql_ctx* x, int mode, double eps) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (x->kernel_timer) {
@@ -404,13 +401,24 @@ static int launch_period(dql_ctx* x, int mode, double eps) {
   }
   if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps); else launch_step_b<double>(x, mode, eps);
   if (x->kernel_timer) { HIP_TRY(hipEventRecord(e1, x->stream)); x->kev.push_back(e0); x->kev.push_back(e1); }
-  PostArgs p;
-  p.qa = x->qa; p.count = x->count; p.accum = x->accum; p.window = x->window; p.alpha_tab = x->alpha_tab; p.n_tab = x->n_tab;
-  p.alpha_min = x->cfg.alpha_min; p.sched = x->sched; p.stats = x->stats; p.tick_ratio = 1.0 / (x->cfg.f_ag * x->cfg.dt);
-  p.learn = (mode == MODE_TRAIN); p.windowed = x->windowed ? 1 : 0; p.per_step = x->cfg.fold_per_step;
-  hipLaunchKernelGGL(k_post, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, p);
-  x->timer_launches += 1;
   HIP_TRY(hipGetLastError());
+  x->pending = (mode == MODE_TRAIN);  // this launch's accumulators wait for the next launch's writer blocks (or a flush)
+  x->step_index += 1;
+  x->timer_launches += 1;
+  return DQL_OK;
+}
+// fold the last launch's accumulators into the master tables now
+static int flush_pending(dql_ctx* x) {
+  if (!x->pending) return DQL_OK;
+  FlushArgs f{x->qa, x->count, x->acc[(x->step_index + 1) & 1], x->window, make_foldk(x), x->windowed ? 1 : 0};
+  hipLaunchKernelGGL(k_flush, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, f);
+  HIP_TRY(hipGetLastError());
+  x->pending = false;
+  return DQL_OK;
+}
+// master -> both acting buffers (after the host or a transfer rewrote the master tables)
+static int publish_master(dql_ctx* x) {
+  for (int k = 0; k < 2; ++k) HIP_TRY(hipMemcpyAsync(x->tb[k], x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
   return DQL_OK;
 }
 
@@ -518,20 +526,20 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   ALLOC(x->si, (size_t)x->n * sizeof(int4));
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
   ALLOC(x->qa_base, DQL_N_CELLS * sizeof(double)); ALLOC(x->count_base, DQL_N_CELLS * sizeof(double));
-  ALLOC(x->accum, 2 * DQL_N_CELLS * sizeof(long long)); ALLOC(x->window_own, 2 * DQL_N_CELLS * sizeof(long long)); x->window = x->window_own;
-  ALLOC(x->sched, sizeof(Sched)); ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n); ALLOC(x->mdpk, sizeof(MdpK<double>));
+  for (int k = 0; k < 2; ++k) { ALLOC(x->tb[k], DQL_N_CELLS * sizeof(double)); ALLOC(x->acc[k], 2 * DQL_N_CELLS * sizeof(long long)); }
+  ALLOC(x->window_own, 2 * DQL_N_CELLS * sizeof(long long)); x->window = x->window_own;
+  ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n); ALLOC(x->mdpk, sizeof(MdpK<double>));
 #undef ALLOC
   HIP_TRY(hipMemsetAsync(x->sr, 0, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size, x->stream));
   HIP_TRY(hipMemsetAsync(x->qa, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->qb, 0, DQL_N_CELLS * sizeof(double), x->stream));
   HIP_TRY(hipMemsetAsync(x->count, 0, DQL_N_CELLS * sizeof(double), x->stream));
   HIP_TRY(hipMemsetAsync(x->qa_base, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->count_base, 0, DQL_N_CELLS * sizeof(double), x->stream));
-  HIP_TRY(hipMemsetAsync(x->accum, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream)); HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  for (int k = 0; k < 2; ++k) { HIP_TRY(hipMemsetAsync(x->tb[k], 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->acc[k], 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream)); }
+  HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
   HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream)); HIP_TRY(hipMemsetAsync(x->d_actions, 2, (size_t)x->n, x->stream));
   rc = upload_mdpk(x);
   if (rc) { dql_destroy(x); return rc; }
   rc = (x->dtype == DQL_F32) ? launch_init<float>(x) : launch_init<double>(x);
-  if (rc) { dql_destroy(x); return rc; }
-  rc = host_sched_init(x);
   if (rc) { dql_destroy(x); return rc; }
   // default alpha table (plateau only): callers install the reference schedule with dql_set_alpha_table
   const double a0 = cfg->alpha_min;
@@ -546,7 +554,7 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->qa_base, x->count_base, x->accum, x->window_own, x->alpha_tab, x->sched, x->stats, x->d_actions, x->mdpk};
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->qa_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -570,6 +578,7 @@ int dql_set_alpha_table(dql_ctx* x, const double* alpha, int32_t n) {
   if (!alpha || n < 1) return fail(DQL_EINVAL, "alpha table must have at least one entry");
   if (alpha[n - 1] != x->cfg.alpha_min) return fail(DQL_EINVAL, "alpha table must end on the alpha_min plateau");
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(x->stream));
   if (x->alpha_tab) HIP_TRY(hipFree(x->alpha_tab));
   x->alpha_tab = nullptr;
@@ -582,9 +591,13 @@ int dql_set_alpha_table(dql_ctx* x, const double* alpha, int32_t n) {
 int dql_set_curriculum(dql_ctx* x, int32_t k) {
   CHECK_CTX(x);
   if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
-  x->cfg.working_curriculum_step = k;
   HIP_TRY(hipSetDevice(x->device));
-  int rc = upload_mdpk(x);
+  int rc = flush_pending(x);
+  if (rc) return rc;
+  rc = publish_master(x);  // the new level starts acting on everything learnt so far
+  if (rc) return rc;
+  x->cfg.working_curriculum_step = k;
+  rc = upload_mdpk(x);
   if (rc) return rc;
   return dql_reset(x, nullptr);
 }
@@ -717,9 +730,15 @@ int dql_get_obs(dql_ctx* x, double* out) {
 }
 
 // ---- tables ----
+int dql_flush(dql_ctx* x) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  return flush_pending(x);
+}
 int dql_get_tables(dql_ctx* x, double* qa, double* qb, double* count) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   const size_t B = DQL_N_CELLS * sizeof(double);
   if (qa) HIP_TRY(hipMemcpyAsync(qa, x->qa, B, hipMemcpyDeviceToHost, x->stream));
   if (qb) HIP_TRY(hipMemcpyAsync(qb, x->qb, B, hipMemcpyDeviceToHost, x->stream));
@@ -730,10 +749,12 @@ int dql_get_tables(dql_ctx* x, double* qa, double* qb, double* count) {
 int dql_set_tables(dql_ctx* x, const double* qa, const double* qb, const double* count) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   const size_t B = DQL_N_CELLS * sizeof(double);
   if (qa) { HIP_TRY(hipMemcpyAsync(x->qa, qa, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->qa_base, qa, B, hipMemcpyHostToDevice, x->stream)); }
   if (qb) HIP_TRY(hipMemcpyAsync(x->qb, qb, B, hipMemcpyHostToDevice, x->stream));
   if (count) { HIP_TRY(hipMemcpyAsync(x->count, count, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->count_base, count, B, hipMemcpyHostToDevice, x->stream)); }
+  if (qa) { int rc = publish_master(x); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }
@@ -741,11 +762,12 @@ int dql_transfer(dql_ctx* x, int32_t k, double ratio) {
   CHECK_CTX(x);
   if (k < 0 || k >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "curriculum step must be in 0..4");
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   const int src = (k - 1 + DQL_MAX_LEVELS) % DQL_MAX_LEVELS;  // k = 0 wraps to the last level (B6)
   hipLaunchKernelGGL(k_transfer, dim3((DQL_CELLS_PER_LEVEL + 255) / 256), dim3(256), 0, x->stream, x->qa, x->qb, k, src, ratio);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
-  return DQL_OK;
+  return publish_master(x);
 }
 
 // ---- multi-GPU exchange ----
@@ -758,6 +780,7 @@ int dql_set_sync_period(dql_ctx* x, int32_t k) {
 int dql_set_windowed(dql_ctx* x, int32_t on) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   if (on && !x->windowed) {
     HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
     HIP_TRY(hipMemcpyAsync(x->count_base, x->count, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
@@ -775,6 +798,7 @@ int dql_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
 int dql_set_window_buffer(dql_ctx* x, void* dev_ptr) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(x->stream));
   x->window = dev_ptr ? (long long*)dev_ptr : x->window_own;
   HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
@@ -785,8 +809,9 @@ int dql_stream_handle(dql_ctx* x, void** s) { CHECK_CTX(x); if (s) *s = (void*)x
 int dql_apply_accum(dql_ctx* x) {
   CHECK_CTX(x);
   if (!x->windowed) return fail(DQL_ESTATE, "dql_apply_accum needs windowed accumulation (dql_set_windowed)");
+  if (x->pending) return fail(DQL_ESTATE, "dql_apply_accum: call dql_flush before reducing the window (the last launch is not in it yet)");
   HIP_TRY(hipSetDevice(x->device));
-  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->window, x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step};
+  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->tb[0], x->tb[1], x->window, make_foldk(x)};
   hipLaunchKernelGGL(k_apply_window, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, a);
   HIP_TRY(hipGetLastError());
   return DQL_OK;
@@ -794,6 +819,7 @@ int dql_apply_accum(dql_ctx* x) {
 int dql_get_accum(dql_ctx* x, int64_t* out) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
   HIP_TRY(hipMemcpyAsync(out, x->window, 2 * DQL_N_CELLS * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
@@ -811,20 +837,20 @@ int dql_stats_get(dql_ctx* x, dql_stats* out) {
   CHECK_CTX(x);
   if (!out) return fail(DQL_EINVAL, "null pointer");
   HIP_TRY(hipSetDevice(x->device));
-  StatsDev s; Sched sc;
+  StatsDev s;
   HIP_TRY(hipMemcpyAsync(&s, x->stats, sizeof(s), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipMemcpyAsync(&sc, x->sched, sizeof(sc), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
-  out->agent_steps = (int64_t)s.agent_steps; out->decisions = (int64_t)s.decisions; out->episodes = (int64_t)s.episodes;
+  out->agent_steps = (int64_t)(x->step_index - x->stats_step_base); out->decisions = (int64_t)s.decisions; out->episodes = (int64_t)s.episodes;
   for (int k = 0; k < DQL_N_CHECK_CODES; ++k) out->by_code[k] = (int64_t)s.by_code[k];
   out->reward_sum = (double)s.reward_fx / (double)(1ll << DQL_TARGET_FRAC_BITS);
-  out->physics_ticks = sc.g0;
+  out->physics_ticks = ticks_before(x, x->step_index);
   return DQL_OK;
 }
 int dql_stats_reset(dql_ctx* x) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream));
+  x->stats_step_base = x->step_index;
   return DQL_OK;
 }
 int dql_timer_start(dql_ctx* x) {
@@ -864,7 +890,6 @@ int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
 int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");
-  if (!strcmp(name, "lds_tables")) { x->lds_tables = value != 0; return DQL_OK; }
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(DQL_EINVAL, "block must be 0, 64, 128 or 256"); x->block = value; return DQL_OK; }
   return fail(DQL_EINVAL, std::string("unknown option ") + name);
 }

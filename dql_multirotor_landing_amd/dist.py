@@ -36,6 +36,7 @@ class TorchWindowReducer:
         self.stream = torch.cuda.ExternalStream(engine.stream_handle(), device=dev)
 
     def all_reduce(self):
+        self.engine.flush()  # the last launch's accumulators enter the window here
         with self.torch.cuda.stream(self.stream):
             self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group)
 

@@ -148,6 +148,9 @@ class Engine:
         _lib.check(self.lib.dql_stream_handle(self._h, C.byref(p)))
         return p.value
 
+    def flush(self):
+        _lib.check(self.lib.dql_flush(self._h))
+
     def apply_accum(self):
         _lib.check(self.lib.dql_apply_accum(self._h))
 

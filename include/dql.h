@@ -188,7 +188,11 @@ int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device
  * NULL restores the context's own buffer.  The buffer is zeroed; the context never frees it. */
 int dql_set_window_buffer(dql_ctx* ctx, void* dev_ptr);
 int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
-int dql_apply_accum(dql_ctx* ctx); /* apply the (all-reduced) accumulators to the base tables, clear them */
+/* The table update of launch j rides in the writer workgroups of launch j+1 (tables act with one period of delay);
+ * dql_flush folds what is still pending (master tables and window) now.  Table getters / setters flush by themselves;
+ * call it before all-reducing the window buffer directly. */
+int dql_flush(dql_ctx* ctx);
+int dql_apply_accum(dql_ctx* ctx); /* fold the (all-reduced) window into the base tables; master and acting tables restart from them */
 int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy, for tests */
 int dql_set_accum(dql_ctx* ctx, const int64_t* in);
 
@@ -200,7 +204,7 @@ int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, 
 /* average device duration of the fused step kernel over the launches made while the kernel timer was armed */
 int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
 int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
-/* tuning knobs: "lds_tables" (0/1: stage the Q tables in LDS), "block" (0 = auto, 64, 128, 256 threads per workgroup) */
+/* tuning knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup) */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 
 /* ---- stateless batch operators (host arrays in/out, computed on the device; drop-in class methods) ---- */

@@ -49,7 +49,11 @@ def _f64(a):
 
 
 class Oracle:
-    """N environments + tables stepped on the CPU with the batched semantics the HIP product implements."""
+    """N environments + tables stepped on the CPU with the batched semantics the HIP product implements.
+
+    Table timing (same as the product): launch j acts on the ACTING tables = master tables with every accumulator up to
+    launch j-2 folded in; while launch j runs, the accumulators of launch j-1 are folded into the MASTER tables, which become
+    the acting tables of launch j+1.  `qa` / `count` (properties) are the master tables with everything folded."""
 
     def __init__(self, cfg: DqlConfig, n_envs: int, seed: int = 42, env_id_offset: int = 0, alpha_tab=None, n_threads: int = 1):
         self.cfg = cfg
@@ -61,10 +65,12 @@ class Oracle:
         L = lib()
         self.env_size = getattr(L, self.pfx + "env_size")()
         self.envs = np.zeros(self.n * self.env_size, dtype=np.uint8)
-        self.qa = np.zeros(N_CELLS, dtype=np.float64)
+        self._qa = np.zeros(N_CELLS, dtype=np.float64)      # master
+        self._count = np.zeros(N_CELLS, dtype=np.float64)
+        self.qa_act = np.zeros(N_CELLS, dtype=np.float64)   # acting copy of Q_table_a
         self.qb = np.zeros(N_CELLS, dtype=np.float64)
-        self.count = np.zeros(N_CELLS, dtype=np.float64)
         self.accum = np.zeros(2 * N_CELLS, dtype=np.int64)
+        self.pending = None
         self.stats = np.zeros(12, dtype=np.int64)
         self.alpha_tab = cfg.alpha_table() if alpha_tab is None else _f64(alpha_tab)
         self.step_index = 0
@@ -74,6 +80,30 @@ class Oracle:
 
     def _fn(self, name):
         return getattr(lib(), self.pfx + name)
+
+    # ---- tables ----
+    @property
+    def qa(self):
+        self.flush()
+        return self._qa
+
+    @property
+    def count(self):
+        self.flush()
+        return self._count
+
+    def set_tables(self, qa=None, qb=None, count=None):
+        self.flush()
+        if qa is not None:
+            self._qa[:] = _f64(qa).ravel(); self.qa_act[:] = self._qa
+            if self.windowed:
+                self.qa_base[:] = self._qa
+        if qb is not None:
+            self.qb[:] = _f64(qb).ravel()
+        if count is not None:
+            self._count[:] = _f64(count).ravel()
+            if self.windowed:
+                self.count_base[:] = self._count
 
     # ---- field access (same field list as the product's dql_get_sim_state) ----
     def n_fields(self):
@@ -96,7 +126,10 @@ class Oracle:
         self._fn("set_fields")(_p(self.envs), C.c_int64(self.n), _p(reals), _p(ints))
 
     def set_curriculum(self, level: int):
-        """New env per level (pkg/trainer.py:172-183): new limits; every env re-enters through reset."""
+        """New env per level (pkg/trainer.py:172-183): new limits; every env re-enters through reset; the new level acts on
+        everything learnt so far."""
+        self.flush()
+        self.qa_act[:] = self._qa
         self.cfg.working_curriculum_step = level
         self.c = self.cfg.to_c()
         reals, ints = self.get_fields()
@@ -104,44 +137,61 @@ class Oracle:
         self.set_fields(reals, ints)
 
     # ---- stepping ----
+    def _contract(self, qa, count, accum):
+        lib().orc_apply_accum(_p(qa), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
+                              C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step))
+
+    def _fold_pending(self):
+        if self.pending is not None:
+            if self.windowed:
+                self.window += self.pending
+            self._contract(self._qa, self._count, self.pending)
+            self.pending = None
+
+    def flush(self):
+        """Fold the last launch's accumulators into the master tables now (the acting tables do not change)."""
+        self._fold_pending()
+
     def _period(self, mode, eps=0.0, actions=None):
         j = self.step_index
         g0 = self.cfg.ticks_before(j)
         n_ticks = self.cfg.ticks_before(j + 1) - g0
         act = None if actions is None else np.ascontiguousarray(actions, dtype=np.uint8)
-        self._fn("agent_periods")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), _p(self.qa), _p(self.qb), _p(self.accum),
+        self._fn("agent_periods")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), _p(self.qa_act), _p(self.qb), _p(self.accum),
                                    _p(self.stats), C.c_int(mode), C.c_double(eps), _p(act) if act is not None else None,
                                    C.c_uint64(self.seed), C.c_int64(self.off), C.c_int64(j), C.c_int64(g0), C.c_int(n_ticks), C.c_int(self.n_threads))
         self.step_index += 1
-
-    def _contract(self, qa, count, accum):
-        lib().orc_apply_accum(_p(qa), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
-                              C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step))
+        # what the writer workgroups of this launch do meanwhile: fold launch j-1, publish the acting tables of launch j+1
+        self._fold_pending()
+        self.qa_act[:] = self._qa
+        if mode == 0:
+            self.pending = self.accum.copy()
+        self.accum[:] = 0
 
     # ---- windowed (multi-rank) semantics: same interface as the product Engine ----
     def set_windowed(self, on: bool):
+        self.flush()
         if on and not self.windowed:
-            self.qa_base = self.qa.copy(); self.count_base = self.count.copy()
+            self.qa_base = self._qa.copy(); self.count_base = self._count.copy()
             self.window = np.zeros(2 * N_CELLS, dtype=np.int64)
         self.windowed = bool(on)
 
     def get_accum(self):
+        self.flush()
         return self.window.copy()
 
     def set_accum(self, a):
         self.window[:] = a
 
     def apply_accum(self):
-        """fold the (all-reduced) window into the base tables and re-base the work tables"""
+        """fold the (all-reduced) window into the base tables; master and acting tables restart from the base"""
+        assert self.pending is None, "flush before reducing the window"
         self._contract(self.qa_base, self.count_base, self.window)
-        self.qa[:] = self.qa_base; self.count[:] = self.count_base
+        self._qa[:] = self.qa_base; self._count[:] = self.count_base; self.qa_act[:] = self.qa_base
 
     def train_steps(self, n_steps: int, eps: float):
         for _ in range(n_steps):
             self._period(0, eps)
-            if self.windowed:
-                self.window += self.accum
-            self._contract(self.qa, self.count, self.accum)
 
     def eval_steps(self, n_steps: int):
         for _ in range(n_steps):
@@ -151,7 +201,11 @@ class Oracle:
         self._period(2, actions=actions)
 
     def transfer(self, k: int, ratio: float):
-        lib().orc_transfer(_p(self.qa), _p(self.qb), C.c_int(k), C.c_double(ratio), C.c_int(5))
+        self.flush()
+        lib().orc_transfer(_p(self._qa), _p(self.qb), C.c_int(k), C.c_double(ratio), C.c_int(5))
+        self.qa_act[:] = self._qa
+        if self.windowed:
+            self.qa_base[:] = self._qa
 
     def stats_dict(self):
         s = self.stats

@@ -2,7 +2,8 @@
 run a million envs in seconds, so here the product is checked against itself and against conservation laws:
   * run-to-run determinism (integer accumulators make the atomics order independent),
   * shard invariance: 4 shards x 262 144 envs (BASELINE configs[3]/[4] per-GPU sizes) with the window accumulators summed by
-    hand every step == one engine of 1 048 576 envs, bit for bit (what the RCCL all-reduce does on 8 GPUs with sync_period 1),
+    hand every step == one engine of 1 048 576 envs on the same sync schedule, bit for bit (what the RCCL all-reduce does on
+    8 GPUs with sync_period 1),
   * conservation: visits added to state_action_counter == env-steps (x2 in the 2-axis config), terminal histogram == episodes,
   * a sample of the big run equals the oracle stepping the same global env ids while both read the same tables."""
 import numpy as np
@@ -56,7 +57,10 @@ def test_shard_invariance_1m_envs(Engine):
     n_total, shards, steps = 1 << 20, 4, 12
     cfg = lambda: DqlConfig(dtype=F32)
     whole = Engine(cfg(), n_total, seed=99)
-    whole.train_steps(steps, 0.5)
+    whole.set_windowed(True)  # same sync schedule as the shards (rank-count invariance): fold the window after every period
+    for _ in range(steps):
+        whole.train_steps(1, 0.5)
+        whole.set_accum(whole.get_accum()); whole.apply_accum()
     parts = [Engine(cfg(), n_total // shards, seed=99, env_id_offset=k * (n_total // shards)) for k in range(shards)]
     for p in parts:
         p.set_windowed(True)
@@ -76,16 +80,18 @@ def test_shard_invariance_1m_envs(Engine):
     np.testing.assert_array_equal(np.concatenate([p.rewards() for p in parts]), r_w)
     dw = whole.stats()["decisions"]
     assert sum(p.stats()["decisions"] for p in parts) == dw == int(cnt_w.sum())
-    # a slice of the big run against the oracle on the same global env ids, both reading the big run's tables
+    # a slice of the big run against the oracle on the same global env ids: before every period the oracle slice is handed the
+    # ACTING tables of the big run (= its master tables as they were two periods earlier: the fold acts with one period of delay)
     from oracle.oracle import Oracle
     lo, m = 777_000, 256
     orc = Oracle(cfg(), m, seed=99, env_id_offset=lo)
     ref = Engine(cfg(), n_total, seed=99)
+    masters = [ref.get_tables()[0].ravel().copy()] * 2  # masters[-2] = acting tables of the next period
     for _ in range(steps):
-        qa, qb, cnt = ref.get_tables()
-        orc.qa[:] = qa.ravel(); orc.qb[:] = qb.ravel(); orc.count[:] = cnt.ravel()
+        orc.qa_act[:] = masters[-2]
         ref.train_steps(1, 0.5)
-        orc._period(0, 0.5); orc.accum[:] = 0
+        masters.append(ref.get_tables()[0].ravel().copy())
+        orc._period(0, 0.5); orc.pending = None
     reals, ints = ref.get_fields()
     o_r, o_i = orc.get_fields()
     np.testing.assert_array_equal(ints[:, lo:lo + m], o_i)

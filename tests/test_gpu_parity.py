@@ -70,24 +70,24 @@ def test_long_run_with_episode_ends(mods):
 @pytest.mark.parametrize("kw", [
     dict(working_curriculum_step=2), dict(working_curriculum_step=4, init_uniform=1, vz_setpoint=-0.4),
     dict(quirks=Q_PAPER), dict(trajectory=TRAJ_EIGHT), dict(per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1),
-    dict(lds=1), dict(block=256), dict(block=128, lds=1),
+    dict(block=256), dict(block=128),
     dict(two_axis=1), dict(two_axis=1, working_curriculum_step=3, init_uniform=1), dict(two_axis=1, quirks=Q_PAPER, trajectory=TRAJ_EIGHT),
     dict(two_axis=1, goal_logic=0, vz_setpoint=-0.4, working_curriculum_step=4, init_uniform=1),
 ])
 def test_config_variants_bit_exact(mods, kw):
     Engine, Oracle = mods
     kw = dict(kw)
-    lds, block = kw.pop("lds", 0), kw.pop("block", 0)
+    block = kw.pop("block", 0)
     n = 320
     eng = Engine(DqlConfig(dtype=F32, **kw), n, seed=11)
-    eng.set_option("lds_tables", lds); eng.set_option("block", block)
+    eng.set_option("block", block)
     orc = Oracle(DqlConfig(dtype=F32, **kw), n, seed=11)
     # start from the reference's stage-4 tables so that greedy actions and bootstraps are non-trivial
     from pathlib import Path
     g = Path(__file__).parent / "golden" / "assets"
     qa, qb, cnt = (np.load(g / f) for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"))
     eng.set_tables(qa, qb, cnt)
-    orc.qa[:] = qa.ravel(); orc.qb[:] = qb.ravel(); orc.count[:] = cnt.ravel()
+    orc.set_tables(qa, qb, cnt)
     eng.train_steps(80, 0.2); orc.train_steps(80, 0.2)
     _compare(eng, orc, exact=True, what=str(kw))
 
@@ -118,8 +118,10 @@ def test_f32_kernel_vs_f64_oracle_one_period(mods):
     e32.train_steps(50, 1.0)
     reals, ints = e32.get_fields()
     o64 = Oracle(DqlConfig(dtype=F64), n, seed=9)
-    o64.train_steps(50, 1.0)  # advance the schedule / tables identically, then overwrite the env state
-    o64.qa[:] = e32.get_tables()[0].ravel(); o64.count[:] = e32.get_tables()[2].ravel()
+    o64.train_steps(50, 1.0)  # advance the schedule identically, then overwrite tables and env state
+    qa32, qb32, cnt32 = e32.get_tables()
+    e32.set_tables(qa32, qb32, cnt32)  # master == acting on both sides from here
+    o64.set_tables(qa32, qb32, cnt32)
     o64.set_fields(reals, ints)
     e32.train_steps(1, 1.0); o64.train_steps(1, 1.0)
     r32, i32 = e32.get_fields(); r64, i64 = o64.get_fields()
@@ -179,7 +181,7 @@ orc = Oracle(DqlConfig(dtype=F32), n, seed=33); orc.set_windowed(True)
 run = ShardedRunner(eng, TorchWindowReducer(eng, 0), sync_period=4)
 run.train_steps(12, 0.7)
 for _ in range(3):
-    orc.train_steps(4, 0.7); orc.apply_accum()
+    orc.train_steps(4, 0.7); orc.flush(); orc.apply_accum()
 eng.sync(); torch.cuda.synchronize()
 qa, qb, cnt = eng.get_tables()
 er, ei = eng.get_fields(); o_r, o_i = orc.get_fields()

@@ -8,7 +8,7 @@ from dql_multirotor_landing_amd.engine import Engine
 
 def run(n, block, lds, dtype, steps):
     e = Engine(DqlConfig(dtype=dtype), n, seed=42)
-    e.set_option("block", block); e.set_option("lds_tables", lds)
+    e.set_option("block", block)
     e.train_steps(30, 1.0); e.sync()
     s0 = e.stats(); e.timer_start()
     e.train_steps(steps, 1.0)
