@@ -411,7 +411,17 @@ DQL_DEV void attitude(const SimK<T>& s, const T (&R)[9], const T (&w)[3], const 
   for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
 }
 // gazebo_motor_model.cpp:434-500 + semi-implicit Euler of one rigid body
-template <typename T> DQL_DEV void motor_and_body(const SimK<T>& s, Env<T>& e, const T (&R)[9], const T (&cmd)[4]) {
+// first-order rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364)
+template <typename T> DQL_DEV void rotor_filter(const SimK<T>& s, Env<T>& e, const T (&cmd)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T ref = cmd[i] < s.omax ? cmd[i] : s.omax;
+    const T a = ref > e.om[i] ? s.aup : s.adn;
+    e.om[i] = fma_(a, e.om[i], (T(1.0) - a) * ref);
+  }
+}
+// forces from the CURRENT rotor speeds (gazebo_motor_model.cpp:434-500) + semi-implicit Euler of one rigid body
+template <typename T> DQL_DEV void plant_step(const SimK<T>& s, Env<T>& e, const T (&R)[9]) {
   const T l = s.l, h = s.h;
   const T w0 = e.w[0], w1 = e.w[1], w2 = e.w[2];
   // thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
@@ -429,12 +439,6 @@ template <typename T> DQL_DEV void motor_and_body(const SimK<T>& s, Env<T>& e, c
   const T tzd = -(s.cd * fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))));  // sum_i (r_i x drag_i)_z / l
   tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, tzd, tz);
   tx = fma_(s.crd, Fbx, tx); ty = fma_(s.crd, Fby, ty);  // rolling moment = (c_r / c_d) * drag force
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const T ref = cmd[i] < s.omax ? cmd[i] : s.omax;
-    const T a = ref > e.om[i] ? s.aup : s.adn;
-    e.om[i] = fma_(a, e.om[i], (T(1.0) - a) * ref);
-  }
   const T ax = fma_(R[0], Fbx, fma_(R[1], Fby, R[2] * Fbz)) * s.inv_m;
   const T ay = fma_(R[3], Fbx, fma_(R[4], Fby, R[5] * Fbz)) * s.inv_m;
   const T az = fma_(R[6], Fbx, fma_(R[7], Fby, R[8] * Fbz)) * s.inv_m - s.g;
@@ -474,19 +478,22 @@ template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e) 
   e.mp_phase = ph;
 }
 // manager_node.py:192-214 + observation_utils.py:77-158
+// scripts/manager_node.py:292-310: plant states of the two PIDs (v_z of the drone, yaw of q_drone q_platform^-1)
+template <typename T> DQL_DEV void manager_states(const T (&R)[9], T cy, T sy, T vz, T& vz_state, T& yw_state) {
+  vz_state = vz;
+  const T A00 = fma_(cy, R[0], sy * R[3]), A01 = fma_(cy, R[1], sy * R[4]);
+  const T A10 = fma_(cy, R[3], -(sy * R[0])), A11 = fma_(cy, R[4], -(sy * R[1]));
+  yw_state = det_atan2(fma_(A10, cy, A11 * sy), fma_(A00, cy, A01 * sy));
+}
+// manager_node.py:192-214 + observation_utils.py:77-158: relative observation, acceleration estimate, contact latch; THEN the
+// platform set-point of the next 10 ms
 template <typename T>
-DQL_DEV void manager_tick(const SimK<T>& s, Env<T>& e, const T (&R)[9], T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
-                          uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step) {
+DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
+                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step) {
   const T dxw = e.mp_x - e.p[0], dyw = e.mp_y - e.p[1];
   const T dvx = e.mp_u - e.v[0], dvy = e.mp_v - e.v[1];
   const T rpx = fma_(cy, dxw, sy * dyw), rpy = fma_(cy, dyw, -(sy * dxw));
   const T rvx = fma_(cy, dvx, sy * dvy), rvy = fma_(cy, dvy, -(sy * dvx));
-  e.vz_state = e.v[2];
-  {
-    const T A00 = fma_(cy, R[0], sy * R[3]), A01 = fma_(cy, R[1], sy * R[4]);
-    const T A10 = fma_(cy, R[3], -(sy * R[0])), A11 = fma_(cy, R[4], -(sy * R[1]));
-    e.yw_state = det_atan2(fma_(A10, cy, A11 * sy), fma_(A00, cy, A01 * sy));
-  }
   T opx = rpx, opy = rpy, ovx = rvx, ovy = rvy;
   if (s.noise_p > T(0.0) || s.noise_v > T(0.0)) {
     uint32_t r[4]; T n0, n1, n2, n3;
@@ -510,6 +517,19 @@ DQL_DEV void manager_tick(const SimK<T>& s, Env<T>& e, const T (&R)[9], T cy, T 
   if (e.flags & FL_CONTACT) e.flags |= FL_OBS_CONTACT; else e.flags &= ~FL_OBS_CONTACT;
   platform_update(s, e);
 }
+// platform extrapolation between manager ticks + bumper contact test
+template <typename T> DQL_DEV void platform_contact(const SimK<T>& s, Env<T>& e) {
+  e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
+  if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+}
+// B = Rx(roll_sp) Ry(pitch_sp) (attitude_controller.py:138-140), constant over one agent period
+template <typename T> DQL_DEV void make_B(T pitch_sp, T roll_sp, T (&B)[9]) {
+  T sp_, cp_, sr_, cr_;
+  det_sincos(pitch_sp, sp_, cp_); det_sincos(roll_sp, sr_, cr_);
+  B[0] = cp_; B[1] = T(0.0); B[2] = sp_;
+  B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_);
+  B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
+}
 
 struct StepOut {  // what one env contributes to the shared tables / counters this period
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
@@ -519,21 +539,27 @@ struct StepOut {  // what one env contributes to the shared tables / counters th
   int decision, done;
 };
 
-// One agent period of one env.  TabPtr: global or LDS pointer to the (read-only) Q tables.
+struct PeriodCtx {
+  uint32_t k0, k1, step_lo, step_hi;
+  int prev_idx, prev_idy, action, action_y;
+  bool is_reset;
+};
+// Start of an agent period: reset placement (landing_simulation_env.py:167-243) or eps-greedy guess + set-point update
+// (double_q_learning.py:110-117, mdp.py:543-560).  TabPtr: pointer to the (read-only) acting Q tables.
 template <typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
-                             uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
-  StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), step_lo = (uint32_t)step_index, step_hi = (uint32_t)((uint64_t)step_index >> 32);
+DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action, uint64_t seed, uint32_t env_id,
+                               long long step_index) {
+  PeriodCtx c;
+  c.k0 = (uint32_t)seed; c.k1 = (uint32_t)(seed >> 32); c.step_lo = (uint32_t)step_index; c.step_hi = (uint32_t)((uint64_t)step_index >> 32);
   uint32_t r[4];
-  philox4x32(step_lo, step_hi, env_id, STREAM_ACTION, k0, k1, r);
-  const bool is_reset = (e.flags & FL_DONE) != 0;
-  const int prev_idx = e.idx_x, prev_idy = e.idx_y;
+  philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION, c.k0, c.k1, r);
+  c.is_reset = (e.flags & FL_DONE) != 0;
+  c.prev_idx = e.idx_x; c.prev_idy = e.idx_y;
   const bool two = s.two_axis != 0;
   int action = 2, action_y = 2;
   uint32_t r2[4] = {0u, 0u, 0u, 0u};
-  if (two) philox4x32(step_lo, step_hi, env_id, STREAM_ACTION + 1u, k0, k1, r2);
-  if (is_reset) {
+  if (two) philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION + 1u, c.k0, c.k1, r2);
+  if (c.is_reset) {
     e.step_count = 0; e.cur_check = 0; e.code = DQL_NON_TERMINAL; e.cum_x = T(0.0); e.cum_y = T(0.0);
     e.pitch_sp = T(0.0); e.roll_sp = T(0.0);
     if (!(s.quirks & DQL_Q_SHAPING_SURVIVES_RESET)) { e.shp_p = T(0.0); e.shp_v = T(0.0); e.shp_a = T(0.0); e.shpy_p = T(0.0); e.shpy_v = T(0.0); e.shpy_a = T(0.0); }
@@ -556,11 +582,11 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     e.flags &= ~FL_WAS_RESET;
     if (mode == MODE_EXTERNAL) { action = ext_action & 3; action_y = two ? (ext_action >> 2) & 3 : 2; }
     else {
-      const int greedy = agent_predict(qa, qb, prev_idx);
+      const int greedy = agent_predict(qa, qb, c.prev_idx);
       const bool explore = (mode == MODE_TRAIN) && ((double)u24<T>(r[0]) < eps);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
       if (two) {
-        const int greedy_y = agent_predict(qa, qb, prev_idy);
+        const int greedy_y = agent_predict(qa, qb, c.prev_idy);
         const bool explore_y = (mode == MODE_TRAIN) && ((double)u24<T>(r2[0]) < eps);
         action_y = explore_y ? (int)(((uint64_t)r2[1] * 3u) >> 32) : greedy_y;
       }
@@ -568,37 +594,19 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     e.pitch_sp = continuous_action(s, e.pitch_sp, action);
     if (two) e.roll_sp = -continuous_action(s, -e.roll_sp, action_y);  // theta_y = -roll
   }
+  c.action = action; c.action_y = action_y;
   e.action = action | (two ? action_y << 2 : 0);
-  T sp_, cp_, sr_, cr_, B[9];
-  det_sincos(e.pitch_sp, sp_, cp_); det_sincos(e.roll_sp, sr_, cr_);
-  B[0] = cp_; B[1] = T(0.0); B[2] = sp_;
-  B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_);
-  B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
-  T R[9], cy, sy;
-  uint32_t mgr_in_step = 0;
-  int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
-  long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
-  for (int i = 0; i < n_ticks; ++i) {
-    DQL_SECTION("rot");
-    quat_to_R(e.q, R); yaw_cs(R, cy, sy);
-    DQL_SECTION("manager");
-    if (phase == 0) { manager_tick(s, e, R, cy, sy, mgr_index, k0, k1, step_lo, step_hi, env_id, mgr_in_step); ++mgr_in_step; ++mgr_index; }
-    phase = (phase + 1 == s.div) ? 0 : phase + 1;
-    DQL_SECTION("pid");
-    const T thrust = pid_output(s, s.vz_kp, s.vz_ki, s.vz_lo, s.vz_hi, s.vz_wind, s.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
-    const T r_cmd = pid_output(s, s.yw_kp, s.yw_ki, s.yw_lo, s.yw_hi, s.yw_wind, s.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
-    T cmd[4];
-    DQL_SECTION("attitude");
-    attitude(s, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
-    DQL_SECTION("motor_body");
-    motor_and_body(s, e, R, cmd);
-    DQL_SECTION("platform_contact");
-    e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
-    if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
-  }
-  DQL_SECTION("epilogue");
-  asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the loop
+  return c;
+}
+// End of an agent period: fresh Euler angles, discretise / check / reward (mdp.py:257-541), TD target (double_q_learning.py:136-145)
+template <typename T, typename TabPtr>
+DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, int mode) {
+  StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
+  const bool two = s.two_axis != 0;
+  const int prev_idx = c.prev_idx, prev_idy = c.prev_idy;
+  asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the tick loop
   const MdpK<T> m = *mp;
+  T R[9];
   quat_to_R(e.q, R);
   const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
   const T pitch = det_atan2(-R[6], cyy);
@@ -613,7 +621,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     e.idx_y = idy;
   }
   e.reward = T(0.0);
-  if (is_reset) return out;
+  if (c.is_reset) return out;
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
   e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
   const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
@@ -633,7 +641,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
     else mask = !done;
     const double target = (double)rew + (m.gamma * boot) * (double)mask;
-    out.cell = prev_idx * 3 + action;
+    out.cell = prev_idx * 3 + c.action;
     out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
     if (two) {  // the y transition updates the same shared tables
       const double y0 = qa[idy * 3], y1 = qa[idy * 3 + 1], y2 = qa[idy * 3 + 2];
@@ -643,11 +651,48 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
       if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
       else mask_y = !done;
       const double target_y = (double)rew_y + (m.gamma * boot_y) * (double)mask_y;
-      out.cell_y = prev_idy * 3 + action_y;
+      out.cell_y = prev_idy * 3 + c.action_y;
       out.target_y_fx = __double2ll_rn(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
     }
   }
   return out;
+}
+
+// One agent period of one env in ONE lane (batches that fill the chip).
+template <typename T, typename TabPtr>
+DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
+                             uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
+  const PeriodCtx c = period_begin(s, e, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
+  T B[9];
+  make_B(e.pitch_sp, e.roll_sp, B);
+  T R[9], cy, sy;
+  uint32_t mgr_in_step = 0;
+  int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
+  long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
+  for (int i = 0; i < n_ticks; ++i) {
+    DQL_SECTION("rot");
+    quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+    DQL_SECTION("manager");
+    if (phase == 0) {
+      manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
+      manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
+      ++mgr_in_step; ++mgr_index;
+    }
+    phase = (phase + 1 == s.div) ? 0 : phase + 1;
+    DQL_SECTION("pid");
+    const T thrust = pid_output(s, s.vz_kp, s.vz_ki, s.vz_lo, s.vz_hi, s.vz_wind, s.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
+    const T r_cmd = pid_output(s, s.yw_kp, s.yw_ki, s.yw_lo, s.yw_hi, s.yw_wind, s.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
+    T cmd[4];
+    DQL_SECTION("attitude");
+    attitude(s, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
+    DQL_SECTION("motor_body");
+    plant_step(s, e, R);
+    rotor_filter(s, e, cmd);
+    DQL_SECTION("platform_contact");
+    platform_contact(s, e);
+  }
+  DQL_SECTION("epilogue");
+  return period_end(s, mp, e, c, qa, mode);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -372,7 +372,7 @@ template <typename T> static int launch_init(dql_ctx* x) {
 static FoldK make_foldk(const dql_ctx* x) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step}; }
 static long long ticks_before(const dql_ctx* x, long long j) { return (long long)std::floor((double)j * (1.0 / (x->cfg.f_ag * x->cfg.dt))); }
 
-template <typename T, int BLOCK> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, double eps, int envs_per_block) {
   const long long j = x->step_index;
   StepArgs<T> a;
   a.c = make_simk<T>(x->cfg);
@@ -383,7 +383,11 @@ template <typename T, int BLOCK> static void launch_step_t(dql_ctx* x, int mode,
   a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->d_actions;
   a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
   a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_ticks = (int)(ticks_before(x, j + 1) - a.g0);
-  a.env_blocks = (int)((x->n + BLOCK - 1) / BLOCK); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
+  a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
+  return a;
+}
+template <typename T, int BLOCK> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+  const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL((k_step<T, BLOCK>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
