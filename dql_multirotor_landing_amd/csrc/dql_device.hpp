@@ -204,6 +204,32 @@ template <typename T> struct SimK {
   uint32_t quirks;
 };
 
+// Per-tick constants held in VECTOR registers for the duration of the tick loop.  The loop wants ~50 constants on top of its
+// loop state; as wave-uniform scalars they overflow the SGPR file and every use of a spilled one costs a v_readlane.  A VALU
+// operand may just as well be a VGPR: one v_mov per constant before the loop (opaque to the compiler, so it stays there).
+DQL_DEV float to_vgpr(float x) { float y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
+template <typename T> struct HotK {
+  T dt, g, inv_m, I[3], inv_I[3], l, h, kf, lkf, kmkf, aup, adn, omax, cd, crd;
+  T kR[3], kW[3], ia, ib, ic;
+  T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
+  T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
+  T bw_k1, bw_k2, bw_inv;
+  T mp_top, mp_hx, mp_hy, bottom;
+};
+DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
+  HotK<float> h;
+#define DQL_H(f) h.f = to_vgpr(s.f)
+  DQL_H(dt); DQL_H(g); DQL_H(inv_m); DQL_H(I[0]); DQL_H(I[1]); DQL_H(I[2]); DQL_H(inv_I[0]); DQL_H(inv_I[1]); DQL_H(inv_I[2]);
+  DQL_H(l); DQL_H(h); DQL_H(kf); DQL_H(lkf); DQL_H(kmkf); DQL_H(aup); DQL_H(adn); DQL_H(omax); DQL_H(cd); DQL_H(crd);
+  DQL_H(kR[0]); DQL_H(kR[1]); DQL_H(kR[2]); DQL_H(kW[0]); DQL_H(kW[1]); DQL_H(kW[2]); DQL_H(ia); DQL_H(ib); DQL_H(ic);
+  DQL_H(vz_kp); DQL_H(vz_ki); DQL_H(vz_lo); DQL_H(vz_hi); DQL_H(vz_wind); DQL_H(vz_sp);
+  DQL_H(yw_kp); DQL_H(yw_ki); DQL_H(yw_lo); DQL_H(yw_hi); DQL_H(yw_wind); DQL_H(yw_sp);
+  DQL_H(bw_k1); DQL_H(bw_inv); DQL_H(mp_top); DQL_H(mp_hx); DQL_H(mp_hy); DQL_H(bottom);
+#undef DQL_H
+  h.bw_k2 = s.bw_k2;  // only steers a wave-uniform branch
+  return h;
+}
+
 enum { FL_DONE = 1, FL_CONTACT = 2, FL_ACC_INIT = 4, FL_WAS_RESET = 8, FL_OBS_CONTACT = 16 };
 enum { MODE_TRAIN = 0, MODE_EVAL = 1, MODE_EXTERNAL = 2 };
 
@@ -343,7 +369,7 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // ---------------------------------------------------------------------------------------------
 // filters / PID  (pkg/filters.py, pkg/pid.py)
 // ---------------------------------------------------------------------------------------------
-template <typename T> DQL_DEV T butterworth(const SimK<T>& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
+template <typename T, typename K> DQL_DEV T butterworth(const K& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
   T acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
   if (c.bw_k2 != T(0.0)) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
   const T value = c.bw_inv * acc;
@@ -351,8 +377,8 @@ template <typename T> DQL_DEV T butterworth(const SimK<T>& c, T x0, T& x1, T& x2
   y3 = y2; y2 = y1; y1 = value;
   return value;
 }
-template <typename T>
-DQL_DEV T pid_output(const SimK<T>& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, T& integ, T& x1, T& x2, T& y1, T& y2, T& y3) {
+template <typename T, typename K>
+DQL_DEV T pid_output(const K& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, T& integ, T& x1, T& x2, T& y1, T& y2, T& y3) {
   // pid.py:62-104 with Kd = 0 (launch/drone.launch:37,51; dql_create rejects Kd != 0)
   const T e0 = sp - state;
   integ = clip(integ + e0 * c.dt, -wind, wind);
@@ -392,8 +418,8 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
   c = R[0] * r; s = R[3] * r;
 }
 // attitude_controller.py:107-156
-template <typename T>
-DQL_DEV void attitude(const SimK<T>& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T r_cmd, T thrust, T (&cmd)[4]) {
+template <typename T, typename K>
+DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T r_cmd, T thrust, T (&cmd)[4]) {
   T D[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { D[j] = fma_(cy, B[j], -(sy * B[3 + j])); D[3 + j] = fma_(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
@@ -412,7 +438,7 @@ DQL_DEV void attitude(const SimK<T>& s, const T (&R)[9], const T (&w)[3], const 
 }
 // gazebo_motor_model.cpp:434-500 + semi-implicit Euler of one rigid body
 // first-order rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364)
-template <typename T> DQL_DEV void rotor_filter(const SimK<T>& s, Env<T>& e, const T (&cmd)[4]) {
+template <typename T, typename K> DQL_DEV void rotor_filter(const K& s, Env<T>& e, const T (&cmd)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const T ref = cmd[i] < s.omax ? cmd[i] : s.omax;
@@ -421,7 +447,7 @@ template <typename T> DQL_DEV void rotor_filter(const SimK<T>& s, Env<T>& e, con
   }
 }
 // forces from the CURRENT rotor speeds (gazebo_motor_model.cpp:434-500) + semi-implicit Euler of one rigid body
-template <typename T> DQL_DEV void plant_step(const SimK<T>& s, Env<T>& e, const T (&R)[9]) {
+template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e, const T (&R)[9]) {
   const T l = s.l, h = s.h;
   const T w0 = e.w[0], w1 = e.w[1], w2 = e.w[2];
   // thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
@@ -518,7 +544,7 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
   platform_update(s, e);
 }
 // platform extrapolation between manager ticks + bumper contact test
-template <typename T> DQL_DEV void platform_contact(const SimK<T>& s, Env<T>& e) {
+template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e) {
   e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
   if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
 }
@@ -658,17 +684,25 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
   return out;
 }
 
-// One agent period of one env in ONE lane (batches that fill the chip).
-template <typename T, typename TabPtr>
+// One agent period of one env in one lane.  HOT: hold the per-tick constants in VGPRs (small batches: one wave per SIMD,
+// registers are free and every avoided v_readlane shortens the dependency-bound stream; at full occupancy it costs a wave).
+template <bool HOT, typename T> struct HotSel { static DQL_DEV const SimK<T>& get(const SimK<T>& s) { return s; } };
+template <> struct HotSel<true, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
+template <bool HOT, typename T, typename TabPtr>
 DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
                              uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   const PeriodCtx c = period_begin(s, e, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
   T B[9];
   make_B(e.pitch_sp, e.roll_sp, B);
+  const auto h = HotSel<HOT, T>::get(s);
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
+#ifndef DQL_TICK_UNROLL
+#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves), neutral at 4 096; 3, 4, 6 are worse
+#endif
+#pragma unroll DQL_TICK_UNROLL
   for (int i = 0; i < n_ticks; ++i) {
     DQL_SECTION("rot");
     quat_to_R(e.q, R); yaw_cs(R, cy, sy);
@@ -680,16 +714,16 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     }
     phase = (phase + 1 == s.div) ? 0 : phase + 1;
     DQL_SECTION("pid");
-    const T thrust = pid_output(s, s.vz_kp, s.vz_ki, s.vz_lo, s.vz_hi, s.vz_wind, s.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
-    const T r_cmd = pid_output(s, s.yw_kp, s.yw_ki, s.yw_lo, s.yw_hi, s.yw_wind, s.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
+    const T thrust = pid_output(h, h.vz_kp, h.vz_ki, h.vz_lo, h.vz_hi, h.vz_wind, h.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
+    const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, h.yw_lo, h.yw_hi, h.yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
     DQL_SECTION("attitude");
-    attitude(s, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
+    attitude(h, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
     DQL_SECTION("motor_body");
-    plant_step(s, e, R);
-    rotor_filter(s, e, cmd);
+    plant_step(h, e, R);
+    rotor_filter(h, e, cmd);
     DQL_SECTION("platform_contact");
-    platform_contact(s, e);
+    platform_contact(h, e);
   }
   DQL_SECTION("epilogue");
   return period_end(s, mp, e, c, qa, mode);

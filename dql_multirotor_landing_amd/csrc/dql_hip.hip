@@ -197,7 +197,7 @@ template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_P
     Env<T> e;
     load_env(e, a.sr, a.si, a.n, i, a.c);
     const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-    const StepOut o = agent_period(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
+    const StepOut o = agent_period<(BLOCK == 64)>(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
     store_env(e, a.sr, a.si, a.n, i, a.c);
     if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
     if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
