@@ -77,3 +77,48 @@ def test_mdp_class_surface():
         m.reward()
     with pytest.raises(ValueError):
         m.continuous_action(0, 1)  # y action while training (pkg/mdp.py:544-545)
+
+
+def test_trainer_promotion_window_logic(tmp_path, monkeypatch):
+    """Promotion rule of pkg/trainer.py:219-236 on vectorised counters: success rate over the most recent >= 100 finished
+    episodes, divisor 100 while fewer have finished, strict '>' against 0.96, transfer ratios per level (reference mode:
+    after the level, B6).  The device engine is replaced by a scripted stand-in (host logic only)."""
+    import dql_multirotor_landing_amd.trainer as T
+
+    class FakeEngine:
+        script = {0: [(40, 40), (40, 40), (40, 30), (60, 59), (60, 59)],      # (episodes, goal successes) per chunk
+                  1: [(200, 150), (200, 193)]}
+        def __init__(self, cfg, n, seed=0, device=0):
+            self.level, self.i = cfg.working_curriculum_step, 0
+            self.tot = {"episodes": 0, "ok": 0, "dec": 0}
+            self.transfers, self.levels = [], []
+        def set_tables(self, *a): pass
+        def get_tables(self):
+            z = np.zeros((5, 3, 3, 3, 7, 3)); return z, z.copy(), z.copy()
+        def set_curriculum(self, k): self.level, self.i = k, 0; self.levels.append(k)
+        def transfer(self, k, r): self.transfers.append((k, r))
+        def train_steps(self, n, eps):
+            sc = self.script.get(self.level, [(100, 100)])
+            e, o = sc[min(self.i, len(sc) - 1)]; self.i += 1
+            self.tot["episodes"] += e; self.tot["ok"] += o; self.tot["dec"] += n * 8
+        def stats(self):
+            by = {k: 0 for k in ("TERMINAL_CONTACT", "TERMINAL_SUCCESS", "TERMINAL_FLYZONE_X", "TERMINAL_FLYZONE_Y", "TERMINAL_FLYZONE_Z",
+                                 "TERMINAL_MINIMUM_ALTITUDE", "TERMINAL_TIMEOUT", "NON_TERMINAL_SUCCESS", "NON_TERMINAL")}
+            by["TERMINAL_SUCCESS"] = self.tot["ok"]
+            return {"episodes": self.tot["episodes"], "by_code": by, "decisions": self.tot["dec"], "reward_sum": 0.0}
+
+    monkeypatch.setattr(T, "Engine", FakeEngine)
+    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=8, chunk_steps=4, checkpoint_every=10**9)
+    hist = tr.curriculum_training()
+    # level 0: 40/100 -> .4; 80/100 -> .8; window (40,40),(40,40),(40,30) = 110/120 -> .917; then (40,30),(60,59) = 89/100 = .89
+    # (older chunks drop once the rest still covers 100 episodes); then (60,59),(60,59) = 118/120 = .983 > .96 -> promoted after 5 chunks
+    assert hist[0]["promoted"] and hist[0]["agent_periods"] == 5 * 4 and hist[0]["episodes"] == 240
+    # level 1: 150/200 = .75, then 193/200 = .965 -> promoted
+    assert hist[1]["promoted"] and hist[1]["agent_periods"] == 2 * 4
+    assert hist[2]["promoted"]  # 100/100 = 1.0 > .96 on the first chunk
+    eng = tr._engine
+    assert eng.levels == [0, 1, 2]
+    assert eng.transfers == [(0, 1.0), (1, 0.8172650252856599), (2, 0.8211253690681617)]  # after each level (B6)
+    tr2 = T.Trainer(curriculum_steps=2, save_path=tmp_path / "run2", n_envs=8, chunk_steps=4, checkpoint_every=10**9, mode="paper")
+    tr2.curriculum_training()
+    assert tr2._engine.transfers == [(1, 0.8172650252856599)]  # paper mode: before level 1, none after
