@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Fixed cost of one launch vs cost per physics tick: agent rate varied so that a period has 1, 5, 11, 22 ticks."""
+import json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.engine import Engine
+for n in (4096, 1048576):
+    for f_ag in (500.0, 100.0, 45.4545, 22.92):
+        e = Engine(DqlConfig(dtype=F32, f_ag=f_ag, t_max=2000.0), n, seed=1)
+        e.train_steps(20, 1.0); e.sync()
+        steps = 400 if n == 4096 else 60
+        e.timer_start(); e.train_steps(steps, 1.0); ms = e.timer_stop()
+        t = e.stats()["physics_ticks"] / e.stats()["agent_steps"]
+        print(json.dumps({"envs": n, "ticks_per_period": round(t, 2), "us_per_step": ms * 1e3 / steps}), flush=True)
+        e.close()
