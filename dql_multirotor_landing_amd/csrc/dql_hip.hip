@@ -158,6 +158,7 @@ template <typename T> struct StepArgs {
   FoldK fold;
   StatsDev* stats;
   const uint8_t* actions;
+  unsigned long long* elog;            // episode log row of this launch or null: [n_waves] done masks, [n_waves] success masks
   long long n, env_id_offset, step_index, g0;
   unsigned long long seed;
   double eps;
@@ -193,6 +194,7 @@ template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_P
   __syncthreads();
   const long long i = (long long)blockIdx.x * BLOCK + tid;
   long long dec = 0, don = 0, rfx = 0;
+  bool goal = false;
   if (i < a.n) {
     Env<T> e;
     load_env(e, a.sr, a.si, a.n, i, a.c);
@@ -202,7 +204,12 @@ template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_P
     if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
     if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
     dec = o.decision; don = o.done; rfx = o.reward_fx;
-    if (o.done) atomicAdd(&a.stats->by_code[e.code], 1ull);
+    if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
+  }
+  if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
+    const unsigned long long dm = __ballot(don != 0), sm = __ballot(goal);
+    const long long w = i >> 6, nw = (a.n + 63) >> 6;
+    if ((tid & 63) == 0 && w < nw) { a.elog[w] = dm; a.elog[nw + w] = sm; }
   }
   // wave64 shuffle reductions -> one LDS atomic per wave -> one global atomic per workgroup
   dec = wave_sum(dec); don = wave_sum(don); rfx = wave_sum(rfx);
@@ -337,6 +344,8 @@ struct dql_ctx {
   int sync_period = 1;
   bool windowed = false;
   int block = 0;  // 0 = auto
+  unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
+  int elog_cap = 0, elog_n = 0;
 };
 
 static int check_config(const dql_config* c) {
@@ -381,6 +390,7 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.qa = x->tb[j & 1]; a.qb = x->qb; a.acc_cur = (unsigned long long*)x->acc[j & 1];
   a.qa_m = x->qa; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
   a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->d_actions;
+  a.elog = x->elog ? x->elog + (size_t)x->elog_n * 2 * (size_t)((x->n + 63) >> 6) : nullptr;
   a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
   a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_ticks = (int)(ticks_before(x, j + 1) - a.g0);
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
@@ -398,6 +408,7 @@ template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps
 }
 // ONE kernel per agent period
 static int launch_period(dql_ctx* x, int mode, double eps) {
+  if (x->elog && x->elog_n >= x->elog_cap) return fail(DQL_ESTATE, "episode log full: read it with dql_episode_log_read before stepping on");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (x->kernel_timer) {
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -406,6 +417,7 @@ static int launch_period(dql_ctx* x, int mode, double eps) {
   if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps); else launch_step_b<double>(x, mode, eps);
   if (x->kernel_timer) { HIP_TRY(hipEventRecord(e1, x->stream)); x->kev.push_back(e0); x->kev.push_back(e1); }
   HIP_TRY(hipGetLastError());
+  if (x->elog) x->elog_n += 1;
   x->pending = (mode == MODE_TRAIN);  // this launch's accumulators wait for the next launch's writer blocks (or a flush)
   x->step_index += 1;
   x->timer_launches += 1;
@@ -558,7 +570,7 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->qa_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk};
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->qa_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -896,6 +908,41 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   if (!name) return fail(DQL_EINVAL, "null option name");
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(DQL_EINVAL, "block must be 0, 64, 128 or 256"); x->block = value; return DQL_OK; }
   return fail(DQL_EINVAL, std::string("unknown option ") + name);
+}
+
+// ---- episode log: which envs finished an episode in each agent period, and which of those reached the goal state ----
+int dql_episode_log_enable(dql_ctx* x, int32_t capacity_periods) {
+  CHECK_CTX(x);
+  if (capacity_periods < 0) return fail(DQL_EINVAL, "capacity_periods must be >= 0");
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (x->elog) { HIP_TRY(hipFree(x->elog)); x->elog = nullptr; }
+  x->elog_cap = 0; x->elog_n = 0;
+  if (capacity_periods == 0) return DQL_OK;
+  const size_t nw = (size_t)((x->n + 63) >> 6);
+  if (hipMalloc((void**)&x->elog, (size_t)capacity_periods * 2 * nw * sizeof(unsigned long long)) != hipSuccess) { x->elog = nullptr; return fail(DQL_ENOMEM, "hipMalloc(episode log) failed"); }
+  x->elog_cap = capacity_periods;
+  return DQL_OK;
+}
+int dql_episode_log_read(dql_ctx* x, uint64_t* done_masks, uint64_t* goal_masks, int32_t max_periods, int32_t* n_periods) {
+  CHECK_CTX(x);
+  if (!x->elog) return fail(DQL_ESTATE, "episode log is not enabled (dql_episode_log_enable)");
+  if (!n_periods) return fail(DQL_EINVAL, "n_periods must not be null");
+  if (x->elog_n > max_periods || (x->elog_n && (!done_masks || !goal_masks))) return fail(DQL_EINVAL, "output buffers hold fewer periods than were logged");
+  const size_t nw = (size_t)((x->n + 63) >> 6);
+  HIP_TRY(hipSetDevice(x->device));
+  if (x->elog_n) {
+    std::vector<unsigned long long> h((size_t)x->elog_n * 2 * nw);
+    HIP_TRY(hipMemcpyAsync(h.data(), x->elog, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    for (int p = 0; p < x->elog_n; ++p) {
+      memcpy(done_masks + (size_t)p * nw, &h[(size_t)p * 2 * nw], nw * sizeof(uint64_t));
+      memcpy(goal_masks + (size_t)p * nw, &h[(size_t)p * 2 * nw + nw], nw * sizeof(uint64_t));
+    }
+  }
+  *n_periods = x->elog_n;
+  x->elog_n = 0;
+  return DQL_OK;
 }
 
 // ---- stateless operators ----

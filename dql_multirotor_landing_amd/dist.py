@@ -84,3 +84,45 @@ class ShardedRunner:
             self.reducer.all_reduce()
             self.engine.apply_accum()
         self._since = 0
+
+
+class TorchComm:
+    """The Trainer's control-plane exchanges: per-chunk counters (sum) and episode logs (gather in rank order = global env
+    order).  Tensors live on the GPU for the nccl (= RCCL) backend, on the host for gloo."""
+
+    def __init__(self, group=None, device_index: int = 0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.device_index = device_index
+        self.dev = torch.device("cuda", device_index) if self.backend == "nccl" else torch.device("cpu")
+
+    @staticmethod
+    def from_env(device_index: int = 0):
+        """A communicator when this process is one rank of an initialised torch.distributed job with more than one rank."""
+        import sys
+        td = sys.modules.get("torch.distributed")  # never imports torch by itself: a single-GPU run does not need it
+        if td is None or not td.is_available() or not td.is_initialized() or td.get_world_size() < 2:
+            return None
+        return TorchComm(None, device_index)
+
+    def reducer(self, engine):
+        if self.backend == "nccl":
+            return TorchWindowReducer(engine, self.device_index, self.group)
+        return HostWindowReducer(engine, self.group)
+
+    def all_reduce_sum(self, v: np.ndarray) -> np.ndarray:
+        t = self.torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def all_gather_masks(self, done: np.ndarray, goal: np.ndarray):
+        """[P, W] uint64 on every rank (same shape) -> [P, world * W], rank order"""
+        loc = np.stack([np.ascontiguousarray(done, dtype=np.uint64), np.ascontiguousarray(goal, dtype=np.uint64)])
+        t = self.torch.from_numpy(loc.view(np.int64)).to(self.dev)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        full = np.concatenate([o.cpu().numpy().view(np.uint64) for o in out], axis=2)
+        return full[0], full[1]

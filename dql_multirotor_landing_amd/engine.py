@@ -193,6 +193,20 @@ class Engine:
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.dql_set_option(self._h, name.encode(), int(value)))
 
+    # ---- episode log (completion order for the promotion rule, pkg/trainer.py:218-232) ----
+    def episode_log_enable(self, capacity_periods: int):
+        _lib.check(self.lib.dql_episode_log_enable(self._h, int(capacity_periods)))
+        self._elog_cap = int(capacity_periods)
+
+    def episode_log_read(self):
+        """(done, goal) uint64[n_periods, n_waves]: bit l of word w = env 64 w + l finished an episode / finished it in the goal state"""
+        nw = (self.n + 63) // 64
+        done = np.zeros((self._elog_cap, nw), dtype=np.uint64)
+        goal = np.zeros((self._elog_cap, nw), dtype=np.uint64)
+        k = C.c_int32()
+        _lib.check(self.lib.dql_episode_log_read(self._h, _p(done), _p(goal), self._elog_cap, C.byref(k)))
+        return done[:k.value], goal[:k.value]
+
     def state_bytes_per_env(self) -> int:
         b = C.c_int64()
         _lib.check(self.lib.dql_state_bytes_per_env(self._h, C.byref(b)))

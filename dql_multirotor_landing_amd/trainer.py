@@ -4,7 +4,20 @@
 GPU: `Engine.train_steps` is the inner `while not done` body (guess, env.step, agent.update) of every env, and the
 host only evaluates the episode-indexed schedules between chunks of agent periods.
 
-Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet.
+Promotion (`promotion_rule`): "ordered" is the reference's rule itself — a deque of the last 100 episodes, checked after
+every episode — on the episodes of the first `judge_envs` envs taken in the order they START (promotion.py explains why not
+in the order they finish; the engine's episode log supplies the order); "aggregate" is the stricter large-sample form
+(success rate over all episodes of the most recent chunks covering >= 100 episodes).  Like
+the reference (:187, the `for` over `max_num_episodes` simply ends), a level whose episode budget runs out without a
+promotion still hands over to the next level.
+
+Multi-GPU (BASELINE config 4): when `torch.distributed` is initialised with world size > 1 every rank runs
+this same loop on its shard of the `n_envs` global envs; tables synchronise every `sync_period` agent periods through
+dist.ShardedRunner, the per-chunk counters are all-reduced and the judged envs' episode logs all-gathered (rank order = global
+env order), so every rank takes the same promotion decisions and the run does not depend on the number of ranks.
+
+Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
+promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor.
 Trainer state is saved as JSON (never pickle); the reference's resume path is broken (B12), this one works."""
 from __future__ import annotations
 
@@ -20,8 +33,10 @@ from typing import Any, Dict, Optional
 import numpy as np
 
 from .config import DqlConfig, F32, Q_PAPER, Q_REFERENCE
+from .dist import ShardedRunner, TorchComm, shard_range
 from .double_q_learning import ASSETS_PATH, DoubleQLearningAgent, StateAction
 from .engine import Engine
+from .promotion import EpisodeOrder, PromotionWindow
 
 _TS = r"%d-%m-%Y %H:%M:%S"
 
@@ -34,10 +49,13 @@ class Trainer:
                  t_max: int = 20, z_init: float = 4.0, f_ag: float = 22.92, p_max: float = 4.5,
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
-                 fold_per_step: int = 0, eps_floor: float = 0.0) -> None:
+                 fold_per_step: int = 0, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
+                 judge_envs: Optional[int] = 4096, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
+        if promotion_rule not in ("ordered", "aggregate"):
+            raise ValueError("promotion_rule must be 'ordered' or 'aggregate'")
         if not double_q_learning_agent:
             double_q_learning_agent = DoubleQLearningAgent(curriculum_steps)
         self._double_q_learning_agent = double_q_learning_agent
@@ -61,6 +79,12 @@ class Trainer:
         self._chunk_steps, self._checkpoint_every, self._quiet = int(chunk_steps), int(checkpoint_every), quiet
         self._max_steps_per_level = max_steps_per_level
         self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
+        self._promotion_rule, self._sync_period = promotion_rule, int(sync_period)
+        self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
+        self._comm = comm if comm is not None else TorchComm.from_env(device)  # None: single process
+        self._reducer_factory = reducer_factory
+        self._rank = self._comm.rank if self._comm else 0
+        self._world = self._comm.world if self._comm else 1
         self.history = []  # one record per finished curriculum level
         self._engine: Optional[Engine] = None
 
@@ -103,6 +127,8 @@ class Trainer:
 
     def save(self) -> None:
         self._pull_tables()
+        if self._rank != 0:  # replicas are identical after a sync: rank 0 writes
+            return
         self._save_path.mkdir(parents=True, exist_ok=True)
         with open(self._save_path / "trainer.json", "w") as f:
             json.dump(self._state_dict(), f, indent=1)
@@ -150,12 +176,55 @@ class Trainer:
         self._double_q_learning_agent._unpad(qa.reshape(-1), qb.reshape(-1), cnt.reshape(-1))
 
     # ---- pkg/trainer.py:169-245 ----
+    def _make_engine(self, cfg):
+        if self._world > 1 or self._reducer_factory is not None:
+            if self._chunk_steps % self._sync_period:
+                raise ValueError("chunk_steps must be a multiple of sync_period (checkpoints and promotions happen on synchronised tables)")
+            lo, hi = shard_range(self._n_envs, self._rank, self._world)
+            eng = Engine(cfg, hi - lo, seed=self._seed, device=self._device, env_id_offset=lo)
+            make = self._reducer_factory if self._reducer_factory is not None else self._comm.reducer
+            return eng, ShardedRunner(eng, make(eng), self._sync_period)
+        eng = Engine(cfg, self._n_envs, seed=self._seed, device=self._device)
+        return eng, ShardedRunner(eng, None)
+
+    def _chunk_counters(self, s, s_prev):
+        v = np.array([s["episodes"] - s_prev["episodes"], s["by_code"]["TERMINAL_SUCCESS"] - s_prev["by_code"]["TERMINAL_SUCCESS"],  # "Goal state reached" only (B17)
+                      s["decisions"] - s_prev["decisions"], s["reward_sum"] - s_prev["reward_sum"]], dtype=np.float64)
+        return self._comm.all_reduce_sum(v) if self._comm else v
+
+    def _judge_layout(self):
+        """Which bit columns of the (gathered) episode log are judged envs: global ids 0 .. judge_envs-1, rank by rank."""
+        cnt = []
+        for r in range(self._world):
+            lo, hi = shard_range(self._n_envs, r, self._world)
+            cnt.append(int(np.clip(self._judge_envs - lo, 0, hi - lo)))
+        w = max(1, max((c + 63) // 64 for c in cnt))
+        valid = np.concatenate([np.arange(w * 64) < c for c in cnt])
+        return cnt[self._rank], w, valid
+
+    def _judge_masks(self, done, goal, cnt, w):
+        """this rank's log restricted to its judged envs, padded to w words per period"""
+        P = done.shape[0]
+        out = np.zeros((2, P, w), dtype=np.uint64)
+        k = min(w, done.shape[1])
+        keep = np.packbits(np.arange(k * 64) < cnt, bitorder="little").view(np.uint64)
+        out[0, :, :k] = done[:, :k] & keep; out[1, :, :k] = goal[:, :k] & keep
+        if self._comm:
+            return self._comm.all_gather_masks(out[0], out[1])
+        return out[0], out[1]
+
     def curriculum_training(self):
         t_start = time.perf_counter()
         cfg = self._config(self._working_curriculum_step)
-        self._engine = Engine(cfg, self._n_envs, seed=self._seed, device=self._device)
+        self._engine, runner = self._make_engine(cfg)
         self._push_tables()
         eng = self._engine
+        ordered = self._promotion_rule == "ordered"
+        if ordered:
+            eng.episode_log_enable(self._chunk_steps)
+        pw = PromotionWindow(self._successive_successful_episodes, self._success_rate)
+        j_cnt, j_w, j_valid = self._judge_layout()
+        order = EpisodeOrder(j_valid.size, j_valid)
         for self._working_curriculum_step in range(self._working_curriculum_step, self._curriculum_steps):
             k = self._working_curriculum_step
             if self._mode == "paper" and k >= 1:
@@ -163,22 +232,26 @@ class Trainer:
             eng.set_curriculum(k)  # "Create a new environment to update limits" (:175-183)
             s_prev = eng.stats()
             t_level = time.perf_counter()
-            window = deque()  # (episodes, goal-state successes) per chunk, trimmed to the most recent >= 100 episodes
+            window = deque()  # aggregate rule: (episodes, goal-state successes) per chunk, trimmed to the most recent >= 100 episodes
+            pw.reset(); order.reset()
             episodes = 0
             steps = 0
             promoted = False
+            promoted_at = None
             info: Dict[str, Any] = {}
             chunk_i = 0
             while episodes < self._max_num_episodes:
                 eps = max(self.exploration_rate(episodes, k), self._eps_floor)  # eps_floor = 0 is the reference schedule
-                eng.train_steps(self._chunk_steps, eps)
+                runner.train_steps(self._chunk_steps, eps)
                 steps += self._chunk_steps
                 s = eng.stats()
-                new_eps = s["episodes"] - s_prev["episodes"]
-                new_ok = s["by_code"]["TERMINAL_SUCCESS"] - s_prev["by_code"]["TERMINAL_SUCCESS"]  # "Goal state reached" only (B17)
-                new_dec = s["decisions"] - s_prev["decisions"]
-                new_rew = s["reward_sum"] - s_prev["reward_sum"]
+                new_eps, new_ok, new_dec, new_rew = self._chunk_counters(s, s_prev)
+                new_eps, new_ok = int(new_eps), int(new_ok)
                 s_prev = s
+                hit = None
+                if ordered:
+                    done, goal = self._judge_masks(*eng.episode_log_read(), j_cnt, j_w)
+                    hit = pw.push_flags(order.push(done, goal))
                 episodes += new_eps
                 self._current_episode = episodes
                 self._curriculum_episode_count += new_eps
@@ -197,24 +270,30 @@ class Trainer:
                 if chunk_i % self._checkpoint_every == 0:
                     self.save()
                 self.log(info)
-                if rate > self._success_rate:
+                if (hit is not None) if ordered else (rate > self._success_rate):
                     self._successes = deque([], maxlen=self._successive_successful_episodes)
                     promoted = True
+                    if hit is not None:  # which judged episode (in start order) filled the reference's deque to > success_rate
+                        promoted_at = {"judged_episode": hit + 1}
                     break
                 if self._max_steps_per_level is not None and steps >= self._max_steps_per_level:
                     break
-            self.history.append({"level": k, "promoted": promoted, "episodes": episodes, "agent_periods": steps, "success_rate": info.get("Success rate"),
+            exhausted = not promoted and episodes >= self._max_num_episodes
+            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "episodes": episodes,
+                                 "agent_periods": steps, "success_rate": info.get("Success rate"),
                                  "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start})
             if self._mode == "reference":
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))
             self.save()
-            if not promoted:
+            if not promoted and not exhausted:  # max_steps_per_level (build-specific bound) hit: stop here
                 break
         return self.history
 
     # ---- pkg/trainer.py:247-303: scalar log with the reference's tag names (CSV instead of one TensorBoard file per episode) ----
     def log(self, info: Dict[str, Any], clean=False):
+        if self._rank != 0:
+            return
         path = self._save_path / "logs"
         path.mkdir(parents=True, exist_ok=True)
         f = path / "scalars.csv"

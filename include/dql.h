@@ -207,6 +207,16 @@ int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event
 /* tuning knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup) */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 
+/* ---- episode log (Trainer promotion rule, pkg/trainer.py:218-232) ----
+ * The reference appends one 0/1 ("Goal state reached" in info["Termination condition"]) per finished episode to a
+ * deque(maxlen=100) and promotes when its sum / 100 exceeds 0.96: the rule needs the ORDER in which episodes finish.  With
+ * the log enabled every launch records, per wave of 64 envs, a 64-bit mask of the envs whose episode ended in that agent
+ * period and a mask of those that ended in TERMINAL_SUCCESS; periods in launch order x envs in index order is the global
+ * completion order.  n_waves = (n_envs + 63) / 64.  A launch with a full log fails with DQL_ESTATE. */
+int dql_episode_log_enable(dql_ctx* ctx, int32_t capacity_periods); /* 0 disables and frees */
+/* copies the periods logged since the last read into done_masks / goal_masks [n_periods][n_waves] and empties the log */
+int dql_episode_log_read(dql_ctx* ctx, uint64_t* done_masks, uint64_t* goal_masks, int32_t max_periods, int32_t* n_periods);
+
 /* ---- stateless batch operators (host arrays in/out, computed on the device; drop-in class methods) ---- */
 /* TrainingMdp.discrete_state (pkg/mdp.py:257-333): 4 x double[n] -> packed idx int32[n]; -1 where the reference raises */
 int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const double* rel_v, const double* rel_a,

@@ -105,3 +105,76 @@ def test_two_ranks_windowed_equals_in_process_emulation(tmp_path):
             o.set_accum(tot); o.apply_accum()
     np.testing.assert_array_equal(ranks[0]["qa"], shards[0].qa)
     np.testing.assert_array_equal(ranks[1]["count"], shards[1].count)
+
+
+# ---- the whole curriculum loop (BASELINE config 4 in miniature): Trainer on 2 ranks == Trainer on 1 process ----
+TR_KW = dict(curriculum_steps=3, n_envs=96, chunk_steps=8, sync_period=2, checkpoint_every=10**9, max_num_episodes=150, t_max=3,
+             successive_successful_episodes=10, success_rate=0.25, mode="paper", judge_envs=70)
+
+
+def _oracle_engine_class():
+    from dql_multirotor_landing_amd.config import CHECK_NAMES
+    from oracle.oracle import Oracle
+
+    class OracleEngine:  # the Engine surface the Trainer uses, computed by the CPU oracle (tests only)
+        def __init__(self, cfg, n, seed=42, device=0, env_id_offset=0):
+            self.o = Oracle(cfg, n, seed=seed, env_id_offset=env_id_offset)
+        def __getattr__(self, name):
+            return getattr(self.o, name)
+        def get_tables(self):
+            return self.o.qa.copy(), self.o.qb.copy(), self.o.count.copy()
+        def stats(self):
+            d = self.o.stats_dict()
+            d["by_code"] = {CHECK_NAMES[i]: d["by_code"][i] for i in range(len(CHECK_NAMES))}
+            return d
+    return OracleEngine
+
+
+def _strip(hist):
+    return [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import json
+    import torch.distributed as dist
+    import dql_multirotor_landing_amd.trainer as T
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T.Engine = _oracle_engine_class()
+    tr = T.Trainer(save_path=Path(out_dir) / "run", **TR_KW)  # picks the process group up by itself
+    assert tr._world == 2 and tr._rank == rank
+    hist = tr.curriculum_training()
+    qa, qb, cnt = tr._engine.get_tables()
+    np.savez(Path(out_dir) / f"trainer_rank{rank}.npz", qa=qa, count=cnt)
+    (Path(out_dir) / f"hist{rank}.json").write_text(json.dumps(_strip(hist)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_curriculum_two_ranks_equals_single_process(tmp_path, monkeypatch):
+    """Same promotions (episode and agent period), same episode counts and bit-identical tables whether the 96 envs run on one
+    process or are sharded over two ranks: counters are summed, episode logs gathered in global env order, tables exchanged
+    on the same schedule."""
+    import json
+    import torch.multiprocessing as mp
+    import dql_multirotor_landing_amd.trainer as T
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    h0, h1 = (json.loads((tmp_path / f"hist{r}.json").read_text()) for r in range(2))
+    assert h0 == h1 and [h["level"] for h in h0] == [0, 1, 2]
+    assert (tmp_path / "run" / "Q_table_a.npy").exists()  # rank 0 wrote the checkpoint
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+
+    class LocalReducer:  # world size 1 on the same exchange schedule
+        def __init__(self, eng): self.eng = eng
+        def all_reduce(self): self.eng.flush()
+
+    single = T.Trainer(save_path=tmp_path / "single", reducer_factory=LocalReducer, **TR_KW)
+    hs = json.loads(json.dumps(_strip(single.curriculum_training())))
+    assert hs == h0
+    assert any(h["promoted"] for h in hs) and sum(h["episodes"] for h in hs) > 0
+    qa, _, cnt = single._engine.get_tables()
+    for r in range(2):
+        z = np.load(tmp_path / f"trainer_rank{r}.npz")
+        np.testing.assert_array_equal(z["qa"], qa)
+        np.testing.assert_array_equal(z["count"], cnt)

@@ -168,3 +168,30 @@ def test_error_behaviour_matches_reference_exception_types():
         a.predict((0, 3, 0, 0, 0))
     with pytest.raises(IndexError):
         a.update((0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0), 0.1, 0.99, 1.0)
+
+
+def test_trainer_full_curriculum_hip_equals_oracle_engine(tmp_path, monkeypatch):
+    """The whole curriculum loop (ordered promotion rule, transfers, level switches, windowed table exchange) driven by the HIP
+    engine and by the CPU oracle behind the same Trainer: same promotions, same episode counts, identical tables."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import dql_multirotor_landing_amd.trainer as T
+    from test_dist_gloo import _oracle_engine_class, _strip
+
+    class LocalReducer:
+        def __init__(self, eng): self.eng = eng
+        def all_reduce(self): self.eng.flush()
+
+    kw = dict(curriculum_steps=5, n_envs=320, chunk_steps=16, sync_period=4, checkpoint_every=10**9, max_num_episodes=400, t_max=4,
+              successive_successful_episodes=20, success_rate=0.2, mode="paper", reducer_factory=LocalReducer)
+    hip = T.Trainer(save_path=tmp_path / "hip", **kw)
+    h_hip = _strip(hip.curriculum_training())
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    orc = T.Trainer(save_path=tmp_path / "orc", **kw)
+    h_orc = _strip(orc.curriculum_training())
+    assert h_hip == h_orc and [h["level"] for h in h_hip] == [0, 1, 2, 3, 4]
+    assert any(h["promoted"] for h in h_hip) and any(h["exhausted"] for h in h_hip)
+    for a, b in zip(hip._engine.get_tables(), orc._engine.get_tables()):
+        assert np.array_equal(np.asarray(a).ravel(), np.asarray(b).ravel())
+    assert np.array_equal(np.load(tmp_path / "hip" / "Q_table_a.npy"), np.load(tmp_path / "orc" / "Q_table_a.npy"))

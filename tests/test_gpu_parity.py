@@ -220,3 +220,36 @@ def test_two_axis_bit_exact_f64_and_external_actions(mods):
         eng.step(a); orc.step(a)
     _compare(eng, orc, exact=True, what="two axis external actions")
     assert eng.state_bytes_per_env() > Engine(DqlConfig(dtype=F64), 4, seed=1).state_bytes_per_env()
+
+
+@pytest.mark.parametrize("n,block", [(1000, 0), (1000, 256), (8200, 0)])
+def test_episode_log_matches_oracle(mods, n, block):
+    """Completion order for the promotion rule (pkg/trainer.py:218-232): per agent period and wave of 64 envs, which envs
+    finished an episode and which of those reached the goal state; n not a multiple of 64; read empties the log; a full log
+    refuses the next launch."""
+    Engine, Oracle = mods
+    cfg = dict(dtype=F32, t_max=3.0)
+    eng = Engine(DqlConfig(**cfg), n, seed=11)
+    orc = Oracle(DqlConfig(**cfg), n, seed=11, n_threads=8)
+    if block:
+        eng.set_option("block", block)
+    eng.episode_log_enable(40); orc.episode_log_enable(40)
+    tot = np.zeros(2, dtype=np.int64)
+    for eps in (1.0, 0.2, 0.2):
+        eng.train_steps(40, eps); orc.train_steps(40, eps)
+        de, ge = eng.episode_log_read()
+        do, go = orc.episode_log_read()
+        assert de.shape == (40, (n + 63) // 64) and de.dtype == np.uint64
+        assert np.array_equal(de, do) and np.array_equal(ge, go)
+        assert not (ge & ~de).any()
+        tot += [int(np.bitwise_count(de).sum()), int(np.bitwise_count(ge).sum())]
+    st = eng.stats()
+    assert tot[0] == st["episodes"] > 0 and tot[1] == st["by_code"]["TERMINAL_SUCCESS"] > 0
+    d2, _ = eng.episode_log_read()
+    assert d2.shape[0] == 0
+    eng.train_steps(40, 0.2)
+    with pytest.raises(ValueError):
+        eng.train_steps(1, 0.2)  # DQL_ESTATE: log full
+    eng.episode_log_read()
+    eng.episode_log_enable(0)
+    eng.train_steps(3, 0.2)

@@ -108,7 +108,7 @@ def test_trainer_promotion_window_logic(tmp_path, monkeypatch):
             return {"episodes": self.tot["episodes"], "by_code": by, "decisions": self.tot["dec"], "reward_sum": 0.0}
 
     monkeypatch.setattr(T, "Engine", FakeEngine)
-    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=8, chunk_steps=4, checkpoint_every=10**9)
+    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=8, chunk_steps=4, checkpoint_every=10**9, promotion_rule="aggregate")
     hist = tr.curriculum_training()
     # level 0: 40/100 -> .4; 80/100 -> .8; window (40,40),(40,40),(40,30) = 110/120 -> .917; then (40,30),(60,59) = 89/100 = .89
     # (older chunks drop once the rest still covers 100 episodes); then (60,59),(60,59) = 118/120 = .983 > .96 -> promoted after 5 chunks
@@ -119,6 +119,118 @@ def test_trainer_promotion_window_logic(tmp_path, monkeypatch):
     eng = tr._engine
     assert eng.levels == [0, 1, 2]
     assert eng.transfers == [(0, 1.0), (1, 0.8172650252856599), (2, 0.8211253690681617)]  # after each level (B6)
-    tr2 = T.Trainer(curriculum_steps=2, save_path=tmp_path / "run2", n_envs=8, chunk_steps=4, checkpoint_every=10**9, mode="paper")
+    tr2 = T.Trainer(curriculum_steps=2, save_path=tmp_path / "run2", n_envs=8, chunk_steps=4, checkpoint_every=10**9, mode="paper", promotion_rule="aggregate")
     tr2.curriculum_training()
     assert tr2._engine.transfers == [(1, 0.8172650252856599)]  # paper mode: before level 1, none after
+
+
+def _masks(flags_per_period, n_waves):
+    """rows of {env: goal?} dicts -> (done, goal) uint64[P, n_waves]"""
+    done = np.zeros((len(flags_per_period), n_waves), dtype=np.uint64); goal = done.copy()
+    for r, row in enumerate(flags_per_period):
+        for env, ok in row.items():
+            done[r, env // 64] |= np.uint64(1) << np.uint64(env % 64)
+            if ok:
+                goal[r, env // 64] |= np.uint64(1) << np.uint64(env % 64)
+    return done, goal
+
+
+def test_promotion_window_is_the_reference_deque():
+    """promotion.PromotionWindow == `deque(maxlen=w)`; append per finished episode; `sum / w > rate` (pkg/trainer.py:218-232),
+    episodes ordered by (agent period, env index), state carried across chunks."""
+    from collections import deque
+    from dql_multirotor_landing_amd.promotion import PromotionWindow, failure_positions
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        P, W = int(rng.integers(1, 30)), int(rng.integers(1, 4))
+        p_done, p_ok = rng.uniform(0.01, 0.3), rng.uniform(0.8, 1.0)
+        win, rate = int(rng.choice([5, 10, 100])), float(rng.choice([0.6, 0.8, 0.96, 1.0]))
+        pw, dq, count = PromotionWindow(win, rate), deque([], maxlen=win), 0
+        for chunk in range(4):
+            done = rng.random((P, W * 64)) < p_done
+            ok = done & (rng.random((P, W * 64)) < p_ok)
+            dm = np.packbits(done.reshape(P, W, 64), axis=2, bitorder="little").view(np.uint64).reshape(P, W)
+            gm = np.packbits(ok.reshape(P, W, 64), axis=2, bitorder="little").view(np.uint64).reshape(P, W)
+            brute = None
+            for r in range(P):
+                for i in np.flatnonzero(done[r]):
+                    dq.append(int(ok[r, i]))
+                    if brute is None and sum(dq) / win > rate:
+                        brute = (count, r)
+                    count += 1
+            pos, n_done, per_row = failure_positions(dm, gm)
+            assert n_done == done.sum() and list(per_row) == list(done.sum(axis=1)) and len(pos) == (done & ~ok).sum()
+            assert pw.push(dm, gm) == brute
+            if brute is not None:
+                break
+    # the divisor is the limit while the deque fills: 96 straight successes are not enough, the 97th is (0.97 > 0.96)
+    pw = PromotionWindow(100, 0.96)
+    assert pw.push(*_masks([{e: True for e in range(96)}], 2)) is None
+    assert pw.push(*_masks([{0: True}], 2)) == (96, 0)
+
+
+def test_episode_order_is_start_order():
+    """promotion.EpisodeOrder: completions of concurrently running envs -> goal flags ordered by (start period, env); an episode
+    is released once everything that started before it has finished; padding columns never block the frontier."""
+    from dql_multirotor_landing_amd.promotion import EpisodeOrder
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        N = int(rng.integers(1, 150)); ncols = ((N + 63) // 64) * 64; T = 300; P = int(rng.integers(1, 50))
+        eo = EpisodeOrder(ncols, np.arange(ncols) < N)
+        eps = []
+        done = np.zeros((T, ncols), bool); goal = np.zeros((T, ncols), bool)
+        for e in range(N):
+            t = 0
+            while True:
+                end = t + int(rng.integers(2, 60)) - 1
+                if end >= T:
+                    break
+                ok = bool(rng.random() < 0.7)
+                done[end, e] = True; goal[end, e] = ok; eps.append((t, e, ok, end)); t = end + 1
+        out = []
+        for a in range(0, T, P):
+            pk = lambda m: np.packbits(m.reshape(m.shape[0], -1, 64), axis=2, bitorder="little").view(np.uint64).reshape(m.shape[0], -1)
+            out.append(eo.push(pk(done[a:a + P]), pk(goal[a:a + P])))
+        cur = np.zeros(N, int)
+        for s_, e, ok, end in eps:
+            cur[e] = max(cur[e], end + 1)
+        assert list(np.concatenate(out)) == [ok for s_, e, ok, end in sorted(eps) if s_ < cur.min()]
+
+
+def test_trainer_ordered_promotion_and_budget(tmp_path, monkeypatch):
+    """Ordered rule end to end on a scripted engine: promotion where the reference's per-episode deque passes; a level whose
+    episode budget runs out still hands over to the next level (pkg/trainer.py:187 — the `for` just ends), while the
+    build-specific max_steps_per_level bound stops the run."""
+    import dql_multirotor_landing_amd.trainer as T
+
+    class FakeEngine:
+        def __init__(self, cfg, n, seed=0, device=0):
+            self.n, self.level, self.tot, self.levels, self.transfers, self.rows = n, 0, [0, 0, 0], [], [], []
+        def set_tables(self, *a): pass
+        def get_tables(self):
+            z = np.zeros((5, 3, 3, 3, 7, 3)); return z, z.copy(), z.copy()
+        def set_curriculum(self, k): self.level = k; self.levels.append(k)
+        def transfer(self, k, r): self.transfers.append((k, r))
+        def episode_log_enable(self, cap): self.cap = cap
+        def train_steps(self, n, eps):
+            for _ in range(n):  # every env finishes an episode every period; level 1 never succeeds, others fail only env 0
+                row = {e: (self.level != 1 and e != 0) for e in range(self.n)}
+                self.rows.append(row); self.tot[0] += self.n; self.tot[1] += sum(row.values()); self.tot[2] += self.n
+        def episode_log_read(self):
+            rows, self.rows = self.rows, []
+            return _masks(rows, (self.n + 63) // 64)
+        def stats(self):
+            by = {"TERMINAL_SUCCESS": self.tot[1]}
+            return {"episodes": self.tot[0], "by_code": by, "decisions": self.tot[2], "reward_sum": 0.0}
+
+    monkeypatch.setattr(T, "Engine", FakeEngine)
+    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=50, chunk_steps=4, checkpoint_every=10**9, max_num_episodes=1000)
+    hist = tr.curriculum_training()
+    # level 0: completions F S*49 F S*49 F ...: after 99 episodes the deque holds 97 successes (failures at 0 and 50): 97 / 100 > 0.96
+    assert hist[0]["promoted"] and hist[0]["promoted_at"] == {"judged_episode": 99} and hist[0]["agent_periods"] == 4
+    assert not hist[1]["promoted"] and hist[1]["exhausted"] and hist[1]["episodes"] == 1000  # budget ran out: next level anyway
+    assert hist[2]["promoted"] and [h["level"] for h in hist] == [0, 1, 2]
+    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run2", n_envs=50, chunk_steps=4, checkpoint_every=10**9, max_steps_per_level=8,
+                   initial_curriculum_step=1)
+    hist = tr.curriculum_training()
+    assert [h["level"] for h in hist] == [1] and not hist[0]["promoted"] and not hist[0]["exhausted"]
