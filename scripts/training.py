@@ -29,12 +29,17 @@ if __name__ == "__main__":
     ap.add_argument("--promotion-rule", default="ordered", choices=["ordered", "aggregate"])
     ap.add_argument("--sync-period", type=int, default=1, help="agent periods between table exchanges (multi-GPU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--t-max", type=int, default=20)
+    ap.add_argument("--judge-envs", type=int, default=4096)
+    ap.add_argument("--window", type=int, default=100, help="successive_successful_episodes (reference: 100)")
     a = ap.parse_args()
     import os
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:  # torch first: it brings its own HIP runtime, which has to be the one the process uses
         import torch
         import torch.distributed as dist
+        local %= max(1, torch.cuda.device_count())  # rehearsals with more ranks than GPUs (gloo backend) share the devices
         torch.cuda.set_device(local)
         dist.init_process_group(a.backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", local)} if a.backend == "nccl" else {}))
     import __graft_entry__ as g
@@ -42,7 +47,8 @@ if __name__ == "__main__":
     from dql_multirotor_landing_amd.config import F32, F64
     from dql_multirotor_landing_amd.trainer import Trainer
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local,
-                 promotion_rule=a.promotion_rule, sync_period=a.sync_period,
+                 promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
+                 successive_successful_episodes=a.window,
                  max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
     hist = tr.curriculum_training()
     if rank == 0:

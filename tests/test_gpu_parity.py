@@ -187,6 +187,27 @@ qa, qb, cnt = eng.get_tables()
 er, ei = eng.get_fields(); o_r, o_i = orc.get_fields()
 assert np.array_equal(qa.ravel(), orc.qa) and np.array_equal(cnt.ravel(), orc.count) and cnt.sum() > 0
 assert np.array_equal(ei, o_i) and np.array_equal(er, o_r)
+# the Trainer's control plane over the same backend: counters summed and episode logs gathered as GPU tensors, table
+# exchange through TorchWindowReducer; one rank, so the run must equal the local-exchange run
+import json, tempfile
+import dql_multirotor_landing_amd.trainer as T
+from dql_multirotor_landing_amd.dist import TorchComm
+class LocalReducer:
+    def __init__(self, e): self.e = e
+    def all_reduce(self): self.e.flush()
+kw = dict(n_envs=700, mode="paper", chunk_steps=16, sync_period=4, max_num_episodes=600, curriculum_steps=2, t_max=4,
+          successive_successful_episodes=20, success_rate=0.2, judge_envs=300, checkpoint_every=10**9)
+strip = lambda hist: [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
+d = tempfile.mkdtemp()
+comm = TorchComm(None, 0)
+assert comm.backend == "nccl" and comm.world == 1
+a = T.Trainer(save_path=d + "/a", comm=comm, reducer_factory=comm.reducer, **kw)
+ha = strip(a.curriculum_training())
+b = T.Trainer(save_path=d + "/b", reducer_factory=LocalReducer, **kw)
+hb = strip(b.curriculum_training())
+assert ha == hb and len(ha) == 2, (ha, hb)
+for x, y in zip(a._engine.get_tables(), b._engine.get_tables()):
+    assert np.array_equal(x, y)
 dist.destroy_process_group()
 print("RCCL_OK")
 """
