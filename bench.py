@@ -59,6 +59,41 @@ def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
             "single_thread_value": d1 / t1, "single_thread_sample": f"{envs} envs x {steps} agent periods ({d1} env-steps, {t1:.1f} s)"}
 
 
+def curriculum_leg(args, world, rank, dev_index, dtype):
+    """Second half of BASELINE.json's metric: wall-clock to curriculum stage 4.  The Trainer's loop (reference promotion rule:
+    100-episode deque > 0.96 or the level's episode budget runs out) on the same envs-per-GPU, sharded over the ranks of this
+    job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).  Never fails the bench."""
+    import tempfile
+    try:
+        from dql_multirotor_landing_amd.config import Q_PAPER
+        from dql_multirotor_landing_amd.dist import TorchComm
+        from dql_multirotor_landing_amd.trainer import Trainer
+        with tempfile.TemporaryDirectory() as d:
+            comm = TorchComm(None, dev_index) if world > 1 else None
+            tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
+                         max_num_episodes=args.curriculum_budget, checkpoint_every=10**9, comm=comm)
+            t0 = time.perf_counter()
+            hist = tr.curriculum_training()
+            total = time.perf_counter() - t0
+            if rank != 0:
+                return None
+            sys.path.insert(0, str(ROOT / "scripts"))
+            import simulation
+            ev = {}
+            for name, tables in (("trained", Path(d) / "run"), ("reference_assets", ROOT / "tests" / "golden" / "assets")):
+                h = simulation.evaluate(tables, 4096, 4, flavour="simulation", quirks=Q_PAPER, device=dev_index)
+                g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
+                ev[name] = {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
+        return {"wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total, "mode": "paper",
+                "global_envs": args.envs * world, "episode_budget_per_level": args.curriculum_budget, "sync_period": 2 if world > 1 else 1,
+                "rule": "deque(100) of judged episodes in start order, > 0.96, or budget exhausted (pkg/trainer.py:187,218-232)",
+                "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
+                            "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
+                "stage4_greedy_4096_episodes": ev}
+    except Exception as e:  # noqa: BLE001 - the throughput line must survive
+        return {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +111,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
+    ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
+    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +179,10 @@ def main():
     s2 = eng.stats()
     dec_per_launch = (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])
 
+    curriculum = None
+    if not args.no_curriculum and not args.two_axis:
+        curriculum = curriculum_leg(args, world, rank, dev_index if world > 1 else 0, dtype)
+
     if world > 1:
         t = torch.tensor([wall, float(decisions)], dtype=torch.float64, device=f"cuda:{dev_index}" if args.backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -184,6 +225,8 @@ def main():
             out["large_batch"] = {"envs": args.large_envs, "value": b_dec / (b_ms * 1e-3), "unit": "env-steps/s", "ms_per_step": b_ms / 150,
                                   "hbm_frac_algorithmic": algo_b * b_dec / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             big.close()
+        if curriculum is not None:
+            out["curriculum"] = curriculum
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
         print(json.dumps(out), flush=True)
