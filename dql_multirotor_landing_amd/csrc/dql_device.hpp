@@ -29,6 +29,11 @@
 #else
 #define DQL_SECTION(name) do { } while (0)
 #endif
+#ifdef DQL_WAVE_CLOCK  // diagnostic build (tools/exp_wave_clock.py): the wave's clock when phase DQL_WAVE_CLOCK is complete
+#define DQL_MARK_T(e, k) do { if ((k) == DQL_WAVE_CLOCK) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (e).mark = wall_clock64(); } } while (0)
+#else
+#define DQL_MARK_T(e, k) do { } while (0)
+#endif
 
 namespace dql {
 
@@ -238,6 +243,9 @@ constexpr int NF_REAL = 64, NF_INT = 7;
 
 // per-env state in registers (field order = quad layout, see dql_field_name)
 template <typename T> struct Env {
+#ifdef DQL_WAVE_CLOCK
+  unsigned long long mark;
+#endif
   T p[3], v[3], q[4], w[3], om[4];
   T vz_i, vz_x1, vz_x2, vz_y1, vz_y2, vz_y3, vz_state;
   T yw_i, yw_x1, yw_x2, yw_y1, yw_y2, yw_y3, yw_state;
@@ -360,6 +368,11 @@ DQL_DEV T mdp_reward(const MdpK<T>& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int
 // agent  (pkg/double_q_learning.py)
 // ---------------------------------------------------------------------------------------------
 DQL_DEV int argmax3(double a, double b, double c) { int k = 0; double v = a; if (b > v) { v = b; k = 1; } if (c > v) { k = 2; } return k; }
+struct QRow { double a0, a1, a2, b0, b1, b2; };  // the three action values of one state in both tables
+template <typename TabPtr> DQL_DEV QRow load_qrow(TabPtr qa, TabPtr qb, int idx) {
+  return QRow{qa[idx * 3], qa[idx * 3 + 1], qa[idx * 3 + 2], qb[idx * 3], qb[idx * 3 + 1], qb[idx * 3 + 2]};
+}
+DQL_DEV int agent_predict(const QRow& r) { return argmax3((r.a0 + r.b0) / 2, (r.a1 + r.b1) / 2, (r.a2 + r.b2) / 2); }
 template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int idx) {  // :119-124
   const double a0 = qa[idx * 3], a1 = qa[idx * 3 + 1], a2 = qa[idx * 3 + 2];
   const double b0 = qb[idx * 3], b1 = qb[idx * 3 + 1], b2 = qb[idx * 3 + 2];
@@ -573,8 +586,8 @@ struct PeriodCtx {
 // Start of an agent period: reset placement (landing_simulation_env.py:167-243) or eps-greedy guess + set-point update
 // (double_q_learning.py:110-117, mdp.py:543-560).  TabPtr: pointer to the (read-only) acting Q tables.
 template <typename T, typename TabPtr>
-DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action, uint64_t seed, uint32_t env_id,
-                               long long step_index) {
+DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action, uint64_t seed,
+                               uint32_t env_id, long long step_index) {
   PeriodCtx c;
   c.k0 = (uint32_t)seed; c.k1 = (uint32_t)(seed >> 32); c.step_lo = (uint32_t)step_index; c.step_hi = (uint32_t)((uint64_t)step_index >> 32);
   uint32_t r[4];
@@ -608,7 +621,7 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, TabPtr qa, TabPtr qb
     e.flags &= ~FL_WAS_RESET;
     if (mode == MODE_EXTERNAL) { action = ext_action & 3; action_y = two ? (ext_action >> 2) & 3 : 2; }
     else {
-      const int greedy = agent_predict(qa, qb, c.prev_idx);
+      const int greedy = agent_predict(qx);  // row of prev_idx, requested together with the env state
       const bool explore = (mode == MODE_TRAIN) && ((double)u24<T>(r[0]) < eps);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
       if (two) {
@@ -689,30 +702,24 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
 template <bool HOT, typename T> struct HotSel { static DQL_DEV const SimK<T>& get(const SimK<T>& s) { return s; } };
 template <> struct HotSel<true, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
 template <bool HOT, typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action,
-                             uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
-  const PeriodCtx c = period_begin(s, e, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
+DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
+                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
+  const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
   T B[9];
   make_B(e.pitch_sp, e.roll_sp, B);
   const auto h = HotSel<HOT, T>::get(s);
+  DQL_MARK_T(e, 3);
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
-#ifndef DQL_TICK_UNROLL
-#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves), neutral at 4 096; 3, 4, 6 are worse
-#endif
-#pragma unroll DQL_TICK_UNROLL
-  for (int i = 0; i < n_ticks; ++i) {
-    DQL_SECTION("rot");
-    quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+  auto manager_tick = [&]() {
     DQL_SECTION("manager");
-    if (phase == 0) {
-      manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
-      manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
-      ++mgr_in_step; ++mgr_index;
-    }
-    phase = (phase + 1 == s.div) ? 0 : phase + 1;
+    manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
+    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
+    ++mgr_in_step; ++mgr_index;
+  };
+  auto control_and_plant = [&]() {
     DQL_SECTION("pid");
     const T thrust = pid_output(h, h.vz_kp, h.vz_ki, h.vz_lo, h.vz_hi, h.vz_wind, h.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
     const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, h.yw_lo, h.yw_hi, h.yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
@@ -724,9 +731,58 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     rotor_filter(h, e, cmd);
     DQL_SECTION("platform_contact");
     platform_contact(h, e);
+  };
+  if constexpr (!(HOT && sizeof(T) == 4)) {
+    // big batches (several waves per SIMD, registers decide the occupancy): the plain loop
+#ifndef DQL_TICK_UNROLL
+#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves); 3, 4, 6 are worse
+#endif
+#pragma unroll DQL_TICK_UNROLL
+    for (int i = 0; i < n_ticks; ++i) {
+      DQL_SECTION("rot");
+      quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+      if (phase == 0) manager_tick();
+      phase = (phase + 1 == s.div) ? 0 : phase + 1;
+      control_and_plant();
+    }
+  } else {
+    // one wave per SIMD (small batches, registers are free): the 21 / 22 ticks of a period = a few ticks up to the next manager
+    // tick, then whole manager periods (one manager tick + DQL_GROUP physics ticks, straight-line: no phase test, the filter
+    // histories rotate by renaming instead of moves), then the rest.  Same operations in the same order as the plain loop,
+    // which still serves any other manager_div.  Measured: -4 % at 4 096 envs.
+#ifndef DQL_GROUP
+#define DQL_GROUP 5  // manager_div of the reference: 500 Hz physics / 100 Hz observation
+#endif
+    int left = n_ticks;
+    for (;;) {
+      while (left > 0 && !(s.div == DQL_GROUP && phase == 0 && left >= DQL_GROUP)) {
+        DQL_SECTION("rot");
+        quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+        if (phase == 0) manager_tick();
+        phase = (phase + 1 == s.div) ? 0 : phase + 1;
+        control_and_plant();
+        --left;
+      }
+      if (left == 0) break;
+      do {
+        DQL_SECTION("rot");
+        quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+        manager_tick();
+        control_and_plant();
+#pragma unroll
+        for (int k = 1; k < DQL_GROUP; ++k) {
+          quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+          control_and_plant();
+        }
+        left -= DQL_GROUP;
+      } while (left >= DQL_GROUP);
+    }
   }
   DQL_SECTION("epilogue");
-  return period_end(s, mp, e, c, qa, mode);
+  DQL_MARK_T(e, 4);
+  const StepOut o = period_end(s, mp, e, c, qa, mode);
+  DQL_MARK_T(e, 5);
+  return o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,11 +790,9 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
 //   int4 = { idx_x, idx_y, step_count | cur_check << 16, code | flags << 8 | action << 16 }
 // x-axis configs touch quads 0-10 (+13 when the platform is per-env) and write quad 14.
 // ---------------------------------------------------------------------------------------------
-template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict__ sr, const int4* __restrict__ si, long long n, long long i,
-                                            const SimK<T>& c) {
+template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict__ sr, const int4 iv, long long n, long long i, const SimK<T>& c) {
   const Quad<T> q0 = sr[0 * n + i], q1 = sr[1 * n + i], q2 = sr[2 * n + i], q3 = sr[3 * n + i], q4 = sr[4 * n + i], q5 = sr[5 * n + i];
   const Quad<T> q6 = sr[6 * n + i], q7 = sr[7 * n + i], q8 = sr[8 * n + i], q9 = sr[9 * n + i], q10 = sr[10 * n + i];
-  const int4 iv = si[i];
   e.p[0] = q0.a; e.p[1] = q0.b; e.p[2] = q0.c; e.v[0] = q0.d;
   e.v[1] = q1.a; e.v[2] = q1.b; e.q[0] = q1.c; e.q[1] = q1.d;
   e.q[2] = q2.a; e.q[3] = q2.b; e.w[0] = q2.c; e.w[1] = q2.d;

@@ -165,20 +165,54 @@ template <typename T> struct StepArgs {
   int mode, n_ticks, env_blocks, have_prev, windowed;
 };
 
+// wave64 sum on the DPP path (no LDS permutes, no waits): row_shr 1, 2, 4, 8 build the prefix sums of each row of 16 lanes,
+// row_bcast15 / row_bcast31 carry the row totals across (CDNA keeps the GFX9 broadcasts); lane 63 holds the total
+template <int CTRL, int ROW_MASK> DQL_DEV long long dpp_add64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return v + (long long)(((unsigned long long)hi << 32) | lo);
+}
 DQL_DEV long long wave_sum(long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = dpp_add64<0x111, 0xf>(v); v = dpp_add64<0x112, 0xf>(v); v = dpp_add64<0x114, 0xf>(v); v = dpp_add64<0x118, 0xf>(v);
+  v = dpp_add64<0x142, 0xa>(v); v = dpp_add64<0x143, 0xc>(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), 63);
+  return (long long)(((unsigned long long)hi << 32) | lo);  // wave-uniform
 }
 
 #ifndef DQL_WAVES_PER_EU
 #define DQL_WAVES_PER_EU 1
 #endif
-template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
-  __shared__ unsigned long long sT[DQL_N_CELLS];
-  __shared__ unsigned int sM[DQL_N_CELLS];
+// The step kernel's arguments (constants by value: ~0.5 KB = 8 cache lines) are fetched by the compiler piecemeal, one scalar
+// load + wait per line as registers allow: a chain of scalar-cache misses at the head of every wave.  Touch all lines at once
+// first; the later loads then hit the scalar cache.
+template <int BYTES> DQL_DEV void warm_kernarg() {
+  const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+  static_assert(BYTES > 0x1c0 && BYTES <= 12 * 64, "adjust the touch list to the argument size");
+  asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+               "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(p));
+  if constexpr (BYTES > 0x2c0)  // double-precision constants: four more lines
+    asm volatile("s_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+}
+// LONE: at most one wave per SIMD is resident (small and medium batches): registers are free, so the per-tick constants sit in
+// VGPRs and the tick loop is laid out per manager period (dql_device.hpp: agent_period)
+template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
+  // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
+  // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
+  // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
+  constexpr bool STAGED = BLOCK > 64;
+  __shared__ unsigned long long sT[STAGED ? DQL_N_CELLS : 1];
+  __shared__ unsigned int sM[STAGED ? DQL_N_CELLS : 1];
   __shared__ unsigned long long sStat[4];
+  warm_kernarg<(int)sizeof(StepArgs<T>)>();
   const int tid = threadIdx.x;
+#ifdef DQL_WAVE_CLOCK  // diagnostic build (tools/exp_wave_clock.py): wave start / end times in the episode log instead of the masks
+  const unsigned long long clk0 = wall_clock64();
+#endif
   if ((int)blockIdx.x >= a.env_blocks) {  // table-writer block (whole block takes this path: no barrier is skipped)
     const int c = ((int)blockIdx.x - a.env_blocks) * BLOCK + tid;
     if (c < DQL_N_CELLS) {
@@ -189,45 +223,74 @@ template <typename T, int BLOCK> __global__ __launch_bounds__(BLOCK, DQL_WAVES_P
     return;
   }
   const int ncell = (a.c.working + 1) * DQL_CELLS_PER_LEVEL;
-  for (int c = tid; c < ncell; c += BLOCK) { sT[c] = 0ull; sM[c] = 0u; }
-  if (tid < 4) sStat[tid] = 0ull;
-  __syncthreads();
+  if (STAGED) {
+    for (int c = tid; c < ncell; c += BLOCK) { sT[c] = 0ull; sM[c] = 0u; }
+    if (tid < 4) sStat[tid] = 0ull;
+    __syncthreads();
+  }
   const long long i = (long long)blockIdx.x * BLOCK + tid;
   long long dec = 0, don = 0, rfx = 0;
   bool goal = false;
+#ifdef DQL_WAVE_CLOCK
+  unsigned long long clk1 = 0;
+#endif
   if (i < a.n) {
     Env<T> e;
-    load_env(e, a.sr, a.si, a.n, i, a.c);
+    // the packed ints go first: their state index addresses the acting-table row, whose request then rides along with the
+    // state quads instead of waiting for them (one memory round trip less at the head of the wave)
+    const int4 iv = a.si[i];
+    const QRow qx = load_qrow(a.qa, a.qb, iv.x);
+    load_env(e, a.sr, iv, a.n, i, a.c);
+    DQL_MARK_T(e, 2);
     const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-    const StepOut o = agent_period<(BLOCK == 64)>(a.c, a.mdp, e, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
-    store_env(e, a.sr, a.si, a.n, i, a.c);
-    if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
-    if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
+    const StepOut o = agent_period<LONE>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
+    if (STAGED) {
+      store_env(e, a.sr, a.si, a.n, i, a.c);
+      if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
+      if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
+    } else {  // the atomics go out first: their round trip hides behind the state stores
+      if (o.cell >= 0) { atomicAdd(&a.acc_cur[o.cell], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + o.cell], 1ull); }
+      if (o.cell_y >= 0) { atomicAdd(&a.acc_cur[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + o.cell_y], 1ull); }
+      store_env(e, a.sr, a.si, a.n, i, a.c);
+    }
     dec = o.decision; don = o.done; rfx = o.reward_fx;
     if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
+    DQL_MARK_T(e, 6);
+#ifdef DQL_WAVE_CLOCK
+    clk1 = e.mark;
+#endif
   }
+#ifndef DQL_WAVE_CLOCK
   if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
     const unsigned long long dm = __ballot(don != 0), sm = __ballot(goal);
     const long long w = i >> 6, nw = (a.n + 63) >> 6;
     if ((tid & 63) == 0 && w < nw) { a.elog[w] = dm; a.elog[nw + w] = sm; }
   }
-  // wave64 shuffle reductions -> one LDS atomic per wave -> one global atomic per workgroup
-  dec = wave_sum(dec); don = wave_sum(don); rfx = wave_sum(rfx);
-  if ((tid & 63) == 0) {
-    if (dec) atomicAdd(&sStat[0], (unsigned long long)dec);
-    if (don) atomicAdd(&sStat[1], (unsigned long long)don);
-    if (rfx) atomicAdd(&sStat[2], (unsigned long long)rfx);
-  }
-  __syncthreads();
-  for (int c = tid; c < ncell; c += BLOCK) {
-    const unsigned int m = sM[c];
-    if (m) { atomicAdd(&a.acc_cur[c], sT[c]); atomicAdd(&a.acc_cur[DQL_N_CELLS + c], (unsigned long long)m); }
+#endif
+  // wave64 shuffle reductions -> one atomic per wave (LDS when staged, then one global atomic per workgroup)
+  dec = __popcll(__ballot(dec != 0)); don = __popcll(__ballot(don != 0)); rfx = wave_sum(rfx);
+  if (STAGED) {
+    if ((tid & 63) == 0) {
+      if (dec) atomicAdd(&sStat[0], (unsigned long long)dec);
+      if (don) atomicAdd(&sStat[1], (unsigned long long)don);
+      if (rfx) atomicAdd(&sStat[2], (unsigned long long)rfx);
+    }
+    __syncthreads();
+    for (int c = tid; c < ncell; c += BLOCK) {
+      const unsigned int m = sM[c];
+      if (m) { atomicAdd(&a.acc_cur[c], sT[c]); atomicAdd(&a.acc_cur[DQL_N_CELLS + c], (unsigned long long)m); }
+    }
+    if (tid == 0) { dec = (long long)sStat[0]; don = (long long)sStat[1]; rfx = (long long)sStat[2]; }
   }
   if (tid == 0) {
-    if (sStat[0]) atomicAdd(&a.stats->decisions, sStat[0]);
-    if (sStat[1]) atomicAdd(&a.stats->episodes, sStat[1]);
-    if (sStat[2]) atomicAdd((unsigned long long*)&a.stats->reward_fx, sStat[2]);
+    if (dec) atomicAdd(&a.stats->decisions, (unsigned long long)dec);
+    if (don) atomicAdd(&a.stats->episodes, (unsigned long long)don);
+    if (rfx) atomicAdd((unsigned long long*)&a.stats->reward_fx, (unsigned long long)rfx);
   }
+#ifdef DQL_WAVE_CLOCK
+  if (DQL_WAVE_CLOCK == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); clk1 = wall_clock64(); }
+  if (a.elog && (tid & 63) == 0) { const long long w = i >> 6, nw = (a.n + 63) >> 6; if (w < nw) { a.elog[w] = clk0; a.elog[nw + w] = clk1; } }
+#endif
 }
 
 // fold the last launch's accumulators into the master tables outside a launch (host table access, level switch, rank sync)
@@ -396,15 +459,20 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
   return a;
 }
-template <typename T, int BLOCK> static void launch_step_t(dql_ctx* x, int mode, double eps) {
+template <typename T, int BLOCK, bool LONE> static void launch_step_t(dql_ctx* x, int mode, double eps) {
   const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((k_step<T, BLOCK>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
+  hipLaunchKernelGGL((k_step<T, BLOCK, LONE>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
+  // measured on MI355X (profiles/r1_sweep_blocks.jsonl): single-wave workgroups up to 8192 envs, 256 threads above; the chip
+  // holds 1024 waves at one per SIMD = 65536 envs, up to which the lone-wave layout of the kernel pays
   int block = x->block;
-  if (block == 0) block = (x->n <= 4096) ? 64 : 256;  // measured (profiles/r1_sweep_blocks.jsonl): 256 wins from 8192 envs up
-  if (block == 64) launch_step_t<T, 64>(x, mode, eps); else if (block == 128) launch_step_t<T, 128>(x, mode, eps); else launch_step_t<T, 256>(x, mode, eps);
+  if (block == 0) block = (x->n <= 8192) ? 64 : 256;
+  const bool lone = x->n <= 65536;
+  if (block == 64) { if (lone) launch_step_t<T, 64, true>(x, mode, eps); else launch_step_t<T, 64, false>(x, mode, eps); }
+  else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps);
+  else { if (lone) launch_step_t<T, 256, true>(x, mode, eps); else launch_step_t<T, 256, false>(x, mode, eps); }
 }
 // ONE kernel per agent period
 static int launch_period(dql_ctx* x, int mode, double eps) {

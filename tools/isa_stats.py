@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 src = ROOT / "dql_multirotor_landing_amd" / "csrc" / "dql_hip.hip"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", *sys.argv[2:], "--cuda-device-only", "-S", str(src), "-o", "/tmp/dql.s"], check=True, capture_output=True)
 s = open("/tmp/dql.s").read()
-name = sys.argv[1] if len(sys.argv) > 1 else "_Z6k_stepIfLi64EEv8StepArgsIT_E"
+name = sys.argv[1] if len(sys.argv) > 1 else "_Z6k_stepIfLi64ELb1EEv8StepArgsIT_E"
 a = s.index(name + ":"); b = s.index(".Lfunc_end", a)
 lines = s[a:b].split("\n")
 def is_ins(l): return l.startswith("\t") and not l.strip().startswith(".") and not l.strip().startswith(";")
