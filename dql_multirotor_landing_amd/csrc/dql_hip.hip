@@ -239,7 +239,8 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK, 
     // the packed ints go first: their state index addresses the acting-table row, whose request then rides along with the
     // state quads instead of waiting for them (one memory round trip less at the head of the wave)
     const int4 iv = a.si[i];
-    const QRow qx = load_qrow(a.qa, a.qb, iv.x);
+    // a fresh or reset env has no previous state (idx -1): its row is never used, but the address must stay inside the table
+    const QRow qx = load_qrow(a.qa, a.qb, (unsigned)iv.x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? iv.x : 0);
     load_env(e, a.sr, iv, a.n, i, a.c);
     DQL_MARK_T(e, 2);
     const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
