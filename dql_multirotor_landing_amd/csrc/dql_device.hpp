@@ -625,7 +625,7 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
       const bool explore = (mode == MODE_TRAIN) && ((double)u24<T>(r[0]) < eps);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
       if (two) {
-        const int greedy_y = agent_predict(qa, qb, c.prev_idy);
+        const int greedy_y = agent_predict(qa, qb, c.prev_idy < 0 ? 0 : c.prev_idy);
         const bool explore_y = (mode == MODE_TRAIN) && ((double)u24<T>(r2[0]) < eps);
         action_y = explore_y ? (int)(((uint64_t)r2[1] * 3u) >> 32) : greedy_y;
       }

@@ -780,6 +780,9 @@ int dql_set_sim_ints(dql_ctx* x, const int32_t* in, int32_t nf) {
   CHECK_CTX(x);
   if (!in || nf != NF_INT) return fail(DQL_EINVAL, "in buffer must hold exactly 7 fields x n_envs int32");
   const long long n = x->n;
+  const int n_states = DQL_N_CELLS / DQL_N_ACTIONS;
+  for (long long i = 0; i < n; ++i)  // the state indices address the tables on the device: -1 (no state yet) .. 944
+    if (in[i] < -1 || in[i] >= n_states || in[n + i] < -1 || in[n + i] >= n_states) return fail(DQL_EINVAL, "idx_x / idx_y out of range (-1 .. 944)");
   std::vector<int4> h((size_t)n);
   for (long long i = 0; i < n; ++i)
     h[i] = make_int4(in[0 * n + i], in[1 * n + i], (in[2 * n + i] & 0xffff) | (in[3 * n + i] << 16),

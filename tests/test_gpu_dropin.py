@@ -158,6 +158,15 @@ def test_error_behaviour_matches_reference_exception_types():
         e.set_tables(np.zeros(10))
     with pytest.raises(ValueError):
         e.step(np.zeros(7, dtype=np.uint8))  # ragged action vector
+    reals, ints = e.get_fields()
+    assert (ints[0] == -1).all()             # no state yet: the kernel must not follow this index into the tables
+    e.train_steps(3, 1.0)                     # ... and does not (reset period first)
+    bad = ints.copy(); bad[0, 3] = 945
+    with pytest.raises(ValueError):
+        e.set_fields(reals, bad)              # state indices address device tables: range-checked at the ABI
+    bad[0, 3] = -2
+    with pytest.raises(ValueError):
+        e.set_fields(reals, bad)
     with pytest.raises(ValueError):
         e.set_curriculum(5)
     with pytest.raises(ValueError):
