@@ -384,7 +384,7 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename K> DQL_DEV T butterworth(const K& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
   T acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
-  if (c.bw_k2 != T(0.0)) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
+  if (c.bw_k2 != 0) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
   const T value = c.bw_inv * acc;
   x2 = x1; x1 = x0;
   y3 = y2; y2 = y1; y1 = value;
