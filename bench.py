@@ -70,8 +70,11 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
         from dql_multirotor_landing_amd.trainer import Trainer
         with tempfile.TemporaryDirectory() as d:
             comm = TorchComm(None, dev_index) if world > 1 else None
+            # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
+            # generations of all of them, or a level ends before most envs have finished an episode
+            budget = max(args.curriculum_budget, 16 * args.envs * world)
             tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
-                         max_num_episodes=args.curriculum_budget, checkpoint_every=10**9, comm=comm)
+                         max_num_episodes=budget, checkpoint_every=10**9, comm=comm)
             t0 = time.perf_counter()
             hist = tr.curriculum_training()
             total = time.perf_counter() - t0
@@ -85,7 +88,7 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
                 g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
                 ev[name] = {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
         return {"wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total, "mode": "paper",
-                "global_envs": args.envs * world, "episode_budget_per_level": args.curriculum_budget, "sync_period": 2 if world > 1 else 1,
+                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2 if world > 1 else 1,
                 "rule": "deque(100) of judged episodes in start order, > 0.96, or budget exhausted (pkg/trainer.py:187,218-232)",
                 "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
@@ -112,7 +115,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
-    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000)")
+    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 16 per env")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
