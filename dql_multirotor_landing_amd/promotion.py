@@ -6,11 +6,14 @@ N envs run episodes concurrently, so the order the deque sees has to be defined.
 episodes start and the order in which they finish are the same thing; here they are not, and the COMPLETION order is biased:
 all envs of a level start together, so the first episodes to finish are the short ones — at level 0 the quick successes
 (measured: a 4 096-env run "passes" 97/100 after 24 agent periods with a 37 % policy).  `EpisodeOrder` therefore feeds the
-deque in START order (agent period of the episode's reset, then global env index), which needs no more than the engine's
-episode log (include/dql.h: per agent period and wave, who finished and who finished in the goal state): an episode starts
-the period after the same env's previous one ended.  An episode enters the stream once every episode that started before
-it has finished (time-outs bound the wait to t_max * f_ag periods).  `PromotionWindow` runs the deque rule on an ordered
-0/1 stream without materialising the deque: only the positions of the FAILED episodes matter.
+deque generation by generation: every judged env's first episode of the level (by global env index), then every env's
+second episode, and so on — an order that does not depend on how long episodes take.  (Ordering by the period an episode
+STARTS in was tried and is still biased: envs whose previous episode was a quick success restart together and, with the
+platform's phase carrying over, tend to succeed again — levels were "passed" at a 40–82 % large-sample rate.)  The engine's
+episode log (include/dql.h: per agent period and wave, who finished and who finished in the goal state) is all this needs.
+A generation enters the stream once every judged env has finished it (time-outs bound the wait to t_max * f_ag periods per
+episode).  For one env this is the reference's sequence exactly.  `PromotionWindow` runs the deque rule on an ordered 0/1
+stream without materialising the deque: only the positions of the FAILED episodes matter.
 
 A window of `window` consecutive completions holds at most `max_fail` failures  <=>  two failures that are `max_fail + 1`
 apart in the failure list are more than `window` positions apart, where the not-yet-existing entries before the first
@@ -98,7 +101,8 @@ class PromotionWindow:
 
 
 class EpisodeOrder:
-    """Completion masks of the judged envs -> the episodes' goal flags in START order (see the module docstring)."""
+    """Completion masks of the judged envs -> the episodes' goal flags in the order the deque sees them: every judged env's
+    first episode (by env index), then every env's second episode, and so on (see the module docstring)."""
 
     def __init__(self, n_cols: int, valid=None):
         """n_cols bit columns (64 per mask word); `valid` marks the columns that are real envs (default: all)"""
@@ -107,10 +111,9 @@ class EpisodeOrder:
         self.reset()
 
     def reset(self):
-        """level switch: every env re-enters through reset in the next agent period"""
-        self.start = np.zeros(self.n_cols, dtype=np.int64)  # agent period in which each env's current episode started
-        self.t = 0
-        self._ps = np.zeros(0, dtype=np.int64); self._pe = np.zeros(0, dtype=np.int64); self._pg = np.zeros(0, dtype=bool)
+        """level switch: every env re-enters through reset and starts counting its episodes again"""
+        self.count = np.zeros(self.n_cols, dtype=np.int64)  # episodes each env has finished at this level
+        self._po = np.zeros(0, dtype=np.int64); self._pe = np.zeros(0, dtype=np.int64); self._pg = np.zeros(0, dtype=bool)
 
     @staticmethod
     def _bits(m):
@@ -119,23 +122,21 @@ class EpisodeOrder:
 
     def push(self, done: np.ndarray, goal: np.ndarray) -> np.ndarray:
         """done, goal: uint64[P, n_cols / 64] of the next P agent periods.  Returns the goal flags (bool) of the episodes that
-        became ordered by this chunk."""
+        became ordered by this chunk: a generation is released once every judged env has finished that many episodes."""
         bd, bg = self._bits(done), self._bits(goal)
         r, e = np.nonzero(bd)
         if r.size:
             g = bg[r, e].astype(bool)
-            t = self.t + r
-            o = np.lexsort((t, e))
-            e_s, t_s, g_s = e[o], t[o], g[o]
+            o = np.lexsort((r, e))            # per env in time order
+            e_s, g_s = e[o], g[o]
             first = np.r_[True, e_s[1:] != e_s[:-1]]
-            st = np.where(first, self.start[e_s], np.r_[0, t_s[:-1]] + 1)
-            last = np.r_[e_s[1:] != e_s[:-1], True]
-            self.start[e_s[last]] = t_s[last] + 1
-            self._ps = np.concatenate([self._ps, st]); self._pe = np.concatenate([self._pe, e_s]); self._pg = np.concatenate([self._pg, g_s])
-        self.t += done.shape[0]
-        frontier = self.start[self.valid].min() if self.valid.any() else 0  # every episode that started before it has finished
-        ready = self._ps < frontier
-        rs, re_, rg = self._ps[ready], self._pe[ready], self._pg[ready]
-        self._ps, self._pe, self._pg = self._ps[~ready], self._pe[~ready], self._pg[~ready]
-        o = np.lexsort((re_, rs))
+            run_start = np.maximum.accumulate(np.where(first, np.arange(e_s.size), 0))
+            ordinal = self.count[e_s] + (np.arange(e_s.size) - run_start)   # k-th episode of its env at this level (0-based)
+            np.add.at(self.count, e_s, 1)
+            self._po = np.concatenate([self._po, ordinal]); self._pe = np.concatenate([self._pe, e_s]); self._pg = np.concatenate([self._pg, g_s])
+        frontier = self.count[self.valid].min() if self.valid.any() else 0   # generations every judged env has completed
+        ready = self._po < frontier
+        ro, re_, rg = self._po[ready], self._pe[ready], self._pg[ready]
+        self._po, self._pe, self._pg = self._po[~ready], self._pe[~ready], self._pg[~ready]
+        o = np.lexsort((re_, ro))
         return rg[o]

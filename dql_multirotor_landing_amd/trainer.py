@@ -5,8 +5,9 @@ GPU: `Engine.train_steps` is the inner `while not done` body (guess, env.step, a
 host only evaluates the episode-indexed schedules between chunks of agent periods.
 
 Promotion (`promotion_rule`): "ordered" is the reference's rule itself — a deque of the last 100 episodes, checked after
-every episode — on the episodes of the first `judge_envs` envs taken in the order they START (promotion.py explains why not
-in the order they finish; the engine's episode log supplies the order); "aggregate" is the stricter large-sample form
+every episode — on the episodes of the first `judge_envs` envs, generation by generation: all first episodes of the level
+in env order, then all second ones, ... (promotion.py explains why neither completion nor start order will do; the engine's
+episode log supplies what is needed); "aggregate" is the stricter large-sample form
 (success rate over all episodes of the most recent chunks covering >= 100 episodes).  Like
 the reference (:187, the `for` over `max_num_episodes` simply ends), a level whose episode budget runs out without a
 promotion still hands over to the next level.
@@ -17,7 +18,9 @@ dist.ShardedRunner, the per-chunk counters are all-reduced and the judged envs' 
 env order), so every rank takes the same promotion decisions and the run does not depend on the number of ranks.
 
 Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
-promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor.
+promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor, eps_episode_scale (the reference's
+exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
+generation, so `eps_episode_scale = s` reads the schedule at episodes / s).
 Trainer state is saved as JSON (never pickle); the reference's resume path is broken (B12), this one works."""
 from __future__ import annotations
 
@@ -50,7 +53,7 @@ class Trainer:
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 0, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
-                 judge_envs: Optional[int] = 4096, comm=None, reducer_factory=None) -> None:
+                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -80,6 +83,7 @@ class Trainer:
         self._max_steps_per_level = max_steps_per_level
         self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
         self._promotion_rule, self._sync_period = promotion_rule, int(sync_period)
+        self._eps_episode_scale = float(eps_episode_scale)
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
         self._comm = comm if comm is not None else TorchComm.from_env(device)  # None: single process
         self._reducer_factory = reducer_factory
@@ -241,7 +245,7 @@ class Trainer:
             info: Dict[str, Any] = {}
             chunk_i = 0
             while episodes < self._max_num_episodes:
-                eps = max(self.exploration_rate(episodes, k), self._eps_floor)  # eps_floor = 0 is the reference schedule
+                eps = max(self.exploration_rate(int(episodes / self._eps_episode_scale), k), self._eps_floor)  # scale 1, floor 0: the reference schedule
                 runner.train_steps(self._chunk_steps, eps)
                 steps += self._chunk_steps
                 s = eng.stats()
@@ -273,7 +277,7 @@ class Trainer:
                 if (hit is not None) if ordered else (rate > self._success_rate):
                     self._successes = deque([], maxlen=self._successive_successful_episodes)
                     promoted = True
-                    if hit is not None:  # which judged episode (in start order) filled the reference's deque to > success_rate
+                    if hit is not None:  # which judged episode (generation order) filled the reference's deque to > success_rate
                         promoted_at = {"judged_episode": hit + 1}
                     break
                 if self._max_steps_per_level is not None and steps >= self._max_steps_per_level:

@@ -169,9 +169,10 @@ def test_promotion_window_is_the_reference_deque():
     assert pw.push(*_masks([{0: True}], 2)) == (96, 0)
 
 
-def test_episode_order_is_start_order():
-    """promotion.EpisodeOrder: completions of concurrently running envs -> goal flags ordered by (start period, env); an episode
-    is released once everything that started before it has finished; padding columns never block the frontier."""
+def test_episode_order_is_generation_order():
+    """promotion.EpisodeOrder: completions of concurrently running envs -> goal flags ordered by (episode ordinal of its env,
+    env): all first episodes, then all second ones, ...; a generation is released once every judged env has finished it;
+    padding columns never block the frontier."""
     from dql_multirotor_landing_amd.promotion import EpisodeOrder
     rng = np.random.default_rng(1)
     for trial in range(40):
@@ -180,21 +181,21 @@ def test_episode_order_is_start_order():
         eps = []
         done = np.zeros((T, ncols), bool); goal = np.zeros((T, ncols), bool)
         for e in range(N):
-            t = 0
+            t, k = 0, 0
             while True:
                 end = t + int(rng.integers(2, 60)) - 1
                 if end >= T:
                     break
                 ok = bool(rng.random() < 0.7)
-                done[end, e] = True; goal[end, e] = ok; eps.append((t, e, ok, end)); t = end + 1
+                done[end, e] = True; goal[end, e] = ok; eps.append((k, e, ok)); t = end + 1; k += 1
         out = []
         for a in range(0, T, P):
             pk = lambda m: np.packbits(m.reshape(m.shape[0], -1, 64), axis=2, bitorder="little").view(np.uint64).reshape(m.shape[0], -1)
             out.append(eo.push(pk(done[a:a + P]), pk(goal[a:a + P])))
-        cur = np.zeros(N, int)
-        for s_, e, ok, end in eps:
-            cur[e] = max(cur[e], end + 1)
-        assert list(np.concatenate(out)) == [ok for s_, e, ok, end in sorted(eps) if s_ < cur.min()]
+        cnt = np.zeros(N, int)
+        for k, e, ok in eps:
+            cnt[e] = max(cnt[e], k + 1)
+        assert list(np.concatenate(out)) == [ok for k, e, ok in sorted(eps) if k < cnt.min()]
 
 
 def test_trainer_ordered_promotion_and_budget(tmp_path, monkeypatch):
