@@ -89,7 +89,7 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
                 ev[name] = {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
         return {"wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total, "mode": "paper",
                 "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2 if world > 1 else 1,
-                "rule": "deque(100) of judged episodes in start order, > 0.96, or budget exhausted (pkg/trainer.py:187,218-232)",
+                "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
                 "stage4_greedy_4096_episodes": ev}
