@@ -180,6 +180,9 @@ DQL_DEV long long wave_sum(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);  // wave-uniform
 }
 
+#ifndef DQL_LONE_MAX
+#define DQL_LONE_MAX 262144  // measured (profiles/r1_sweep_envs.jsonl): the lone-wave layout wins up to 262 144 envs, the plain loop from 524 288
+#endif
 #ifndef DQL_WAVES_PER_EU
 #define DQL_WAVES_PER_EU 1
 #endif
@@ -198,9 +201,10 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
     asm volatile("s_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
 }
-// LONE: at most one wave per SIMD is resident (small and medium batches): registers are free, so the per-tick constants sit in
-// VGPRs and the tick loop is laid out per manager period (dql_device.hpp: agent_period)
-template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK, DQL_WAVES_PER_EU) void k_step(StepArgs<T> a) {
+// LONE: the register-hungry layout (per-tick constants in VGPRs, tick loop laid out per manager period: dql_device.hpp,
+// agent_period) for batches of at most a couple of waves per SIMD.  Every instantiation is capped at 2 waves per SIMD: measured
+// at 1 M envs, 3 resident waves are 7 % slower than 2 (and 4 no better), so the allocator may as well keep its registers.
+template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
@@ -466,11 +470,10 @@ template <typename T, int BLOCK, bool LONE> static void launch_step_t(dql_ctx* x
   hipLaunchKernelGGL((k_step<T, BLOCK, LONE>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
-  // measured on MI355X (profiles/r1_sweep_blocks.jsonl): single-wave workgroups up to 8192 envs, 256 threads above; the chip
-  // holds 1024 waves at one per SIMD = 65536 envs, up to which the lone-wave layout of the kernel pays
+  // measured on MI355X (profiles/r1_sweep_blocks.jsonl): single-wave workgroups up to 8192 envs, 256 threads above
   int block = x->block;
   if (block == 0) block = (x->n <= 8192) ? 64 : 256;
-  const bool lone = x->n <= 65536;
+  const bool lone = x->n <= DQL_LONE_MAX;
   if (block == 64) { if (lone) launch_step_t<T, 64, true>(x, mode, eps); else launch_step_t<T, 64, false>(x, mode, eps); }
   else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps);
   else { if (lone) launch_step_t<T, 256, true>(x, mode, eps); else launch_step_t<T, 256, false>(x, mode, eps); }

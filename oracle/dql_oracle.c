@@ -266,6 +266,32 @@ static void mdpc_init(mdpc_t* m, const dql_config* c) {
   m->quirks = c->quirks;
 }
 static inline REAL clip(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* The product's 500 Hz clips are one v_med3_f32 each in float (csrc/dql_device.hpp: clip3); restated here from the gfx9 ISA
+ * pseudo-code so that even signed-zero ties agree: V_MAX_F32 orders -0 < +0, V_MED3_F32 returns the max of the two operands
+ * that are not the maximum (min3 when an operand is NaN).  Double keeps the comparison chain, as the product does. */
+#if ORACLE_F32
+static inline float amd_max_f32(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == 0.0f && b == 0.0f) return (signbit(a) && signbit(b)) ? a : 0.0f;
+  return a >= b ? a : b;
+}
+static inline float amd_min_f32(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == 0.0f && b == 0.0f) return (signbit(a) || signbit(b)) ? -0.0f : a;
+  return a <= b ? a : b;
+}
+static inline REAL clip3(REAL a, REAL b, REAL c) {
+  if (a != a || b != b || c != c) return amd_min_f32(amd_min_f32(a, b), c);
+  const float mx = amd_max_f32(amd_max_f32(a, b), c);
+  if (mx == a) return amd_max_f32(b, c);
+  if (mx == b) return amd_max_f32(a, c);
+  return amd_max_f32(a, b);
+}
+#else
+static inline REAL clip3(REAL x, REAL lo, REAL hi) { return clip(x, lo, hi); }
+#endif
 
 /* pkg/mdp.py:149-158 */
 static inline int latest_valid_level(const REAL* lim, int n, REAL value) {
@@ -400,7 +426,7 @@ typedef struct { REAL kp, ki, kd, lo, hi, windup, setpoint; } pidc_t;
 /* pkg/pid.py:62-104 with delta_t > 0 */
 static inline REAL pid_output(const pidc_t* c, const bwc_t* b, pid_t_* s, REAL delta_t) {
   const REAL e0 = c->setpoint - s->state;
-  s->integ = clip(s->integ + e0 * delta_t, -c->windup, c->windup);
+  s->integ = clip3(s->integ + e0 * delta_t, -c->windup, c->windup);
   const REAL fe = butterworth(b, e0, &s->x1, &s->x2, &s->y1, &s->y2, &s->y3);
   REAL eff = c->kp * fe + c->ki * s->integ;
   if (c->kd != R_(0.0)) {
@@ -409,7 +435,7 @@ static inline REAL pid_output(const pidc_t* c, const bwc_t* b, pid_t_* s, REAL d
     eff = eff + c->kd * fd;
   }
   s->e1 = e0;
-  return clip(eff, c->lo, c->hi);
+  return clip3(eff, c->lo, c->hi);
 }
 /* pkg/filters.py:19-36 */
 static inline REAL kalman1d(REAL* x, REAL* P, REAL Q, REAL Rm, REAL z) {
@@ -518,7 +544,7 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   tx = FMA(s->crd, Fbx, tx); ty = FMA(s->crd, Fby, ty);
   /* rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364) */
   for (int i = 0; i < 4; ++i) {
-    const REAL ref = cmd[i] < s->omax ? cmd[i] : s->omax;
+    const REAL ref = clip3(cmd[i], R_(0.0), s->omax);  /* cmd = sqrt(..) >= +0: min(cmd, omax) */
     const REAL a = ref > e->om[i] ? s->aup : s->adn;
     e->om[i] = FMA(a, e->om[i], (R_(1.0) - a) * ref);
   }
