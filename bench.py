@@ -219,6 +219,19 @@ def main():
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
         }
+        # the roof that actually binds: wave64 f32 VALU instructions through 1024 SIMDs at ~1.9 ns each (tools/micro/valu_rate.hip,
+        # profiles/r1_valu_rate.jsonl), instruction count per env wave from the committed PMC pass
+        pf = ROOT / "profiles" / "r1_pmc_sq_summary.json"
+        if pf.exists() and not args.two_axis and args.dtype == "f32":
+            pm = json.loads(pf.read_text())
+            ref = pm.get(str(args.envs)) or (pm.get("1048576") if args.envs > 262144 else pm.get("4096"))
+            ref_envs = args.envs if str(args.envs) in pm else (1048576 if args.envs > 262144 else 4096)
+            valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64)
+            waves = (args.envs + 63) // 64
+            t_floor = valu_per_wave * 1.9e-9 * max(1.0, waves / 1024.0)  # one wave's stream, or the SIMD's share of all waves
+            out["valu_roofline"] = {"valu_instr_per_env_wave": valu_per_wave, "ns_per_wave64_valu_instr_per_simd": 1.9, "simds": 1024,
+                                    "floor_ms_per_launch": t_floor * 1e3, "frac": t_floor * 1e3 / k_ms if k_ms > 0 else None,
+                                    "note": "informational: the fused step is bound by VALU issue (one wave's instruction stream at small batches, all SIMDs busy at large ones), not by HBM"}
         if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
             # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
             big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis), args.large_envs, seed=42)
