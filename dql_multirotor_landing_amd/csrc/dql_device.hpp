@@ -405,7 +405,12 @@ DQL_DEV T pid_output(const K& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, 
 }
 template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z) {  // filters.py:19-36
   P += Q;
-  const T K = (Rm == T(0.0)) ? T(1.0) : P / (P + Rm);  // P / (P + 0) is exactly 1
+  if (Rm == T(0.0)) {  // wave-uniform (launch files: no measurement noise): P / (P + 0) is exactly 1, no division to pay for
+    x += (z - x);
+    P *= T(0.0);
+    return x;
+  }
+  const T K = P / (P + Rm);
   x += K * (z - x);
   P *= (T(1.0) - K);
   return x;
