@@ -18,7 +18,7 @@ dist.ShardedRunner, the per-chunk counters are all-reduced and the judged envs' 
 env order), so every rank takes the same promotion decisions and the run does not depend on the number of ranks.
 
 Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
-promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor, eps_episode_scale (the reference's
+promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
 exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
 generation, so `eps_episode_scale = s` reads the schedule at episodes / s).
 Trainer state is saved as JSON (never pickle); the reference's resume path is broken (B12), this one works."""
@@ -53,7 +53,8 @@ class Trainer:
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 0, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
-                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, comm=None, reducer_factory=None) -> None:
+                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, comm=None,
+                 reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -84,6 +85,7 @@ class Trainer:
         self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
         self._promotion_rule, self._sync_period = promotion_rule, int(sync_period)
         self._eps_episode_scale = float(eps_episode_scale)
+        self._quirks = (Q_REFERENCE if mode == "reference" else Q_PAPER) if quirks is None else int(quirks)
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
         self._comm = comm if comm is not None else TorchComm.from_env(device)  # None: single process
         self._reducer_factory = reducer_factory
@@ -164,7 +166,7 @@ class Trainer:
 
     # ---- device plumbing ----
     def _config(self, level: int) -> DqlConfig:
-        return DqlConfig(working_curriculum_step=level, dtype=self._dtype, quirks=Q_REFERENCE if self._mode == "reference" else Q_PAPER,
+        return DqlConfig(working_curriculum_step=level, dtype=self._dtype, quirks=self._quirks,
                          t_max=self._t_max, z_init=self._z_init, f_ag=self._f_ag, p_max=self._p_max, init_sigma=self._p_max / 3,
                          gamma=self._gamma, alpha_min=self._alpha_min, alpha_omega=self._omega, fold_per_step=self._fold_per_step)
 
