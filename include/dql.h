@@ -53,7 +53,11 @@ enum {
   DQL_Q_SHAPING_SURVIVES_RESET = 1 << 2,/* B9  pkg/mdp.py:196-197,469-474 */
   DQL_Q_FROZEN_ACC_REFERENCE = 1 << 3,  /* B19 pkg/observation_utils.py:137-150: last_velocity never updated */
   DQL_Q_BOOTSTRAP_ON_POS_CHANGE = 1 << 4,/* B3  pkg/double_q_learning.py:139-145 */
-  DQL_Q_UPDATE_TABLE_A_ONLY = 1 << 5,   /* B1/B2 pkg/double_q_learning.py:101-108,136-146 */
+  DQL_Q_UPDATE_TABLE_A_ONLY = 1 << 5,   /* B1/B2 pkg/double_q_learning.py:101-108,136-146.  Honoured by dql_agent_update (the
+                                         * ordered single-transition operator).  The batched trainer (dql_train_steps) updates
+                                         * Q_table_a only in BOTH modes, as the reference does: Q_table_b changes through
+                                         * dql_set_tables / dql_transfer alone.  True Double Q-learning (coin-picked table, the
+                                         * other table values its greedy action) is not built: DESIGN.md section 10. */
   DQL_Q_REFERENCE = 0x3f
 };
 
