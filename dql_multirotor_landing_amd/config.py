@@ -19,6 +19,7 @@ STATES_PER_LEVEL = 3 * 3 * 3 * N_ANGLES  # 189
 CELLS_PER_LEVEL = STATES_PER_LEVEL * N_ACTIONS  # 567
 N_STATES = MAX_LEVELS * STATES_PER_LEVEL  # 945
 N_CELLS = MAX_LEVELS * CELLS_PER_LEVEL  # 2835
+ACC_LEN = 4 * N_CELLS  # accumulators / exchange window: table a's {target sums, visits}, then table b's (include/dql.h)
 TABLE_SHAPE = (MAX_LEVELS, 3, 3, 3, N_ANGLES, N_ACTIONS)
 TARGET_FRAC_BITS = 26
 

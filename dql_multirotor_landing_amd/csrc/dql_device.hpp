@@ -584,7 +584,7 @@ struct StepOut {  // what one env contributes to the shared tables / counters th
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
   long long target_y_fx;
   long long reward_fx;
-  int cell, cell_y;     // table cells (idx*3+action) or -1
+  int cell, cell_y;     // table * N_CELLS + idx*3+action (table 0 = Q_table_a, 1 = Q_table_b), or -1
   int decision, done;
 };
 
@@ -592,6 +592,7 @@ struct PeriodCtx {
   uint32_t k0, k1, step_lo, step_hi;
   int prev_idx, prev_idy, action, action_y;
   bool is_reset;
+  bool coin, coin_y;  // Double Q-learning: the table this period's transition updates (bit 31 of the action stream's third word)
 };
 // Start of an agent period: reset placement (landing_simulation_env.py:167-243) or eps-greedy guess + set-point update
 // (double_q_learning.py:110-117, mdp.py:543-560).  TabPtr: pointer to the (read-only) acting Q tables.
@@ -644,12 +645,13 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
     if (two) e.roll_sp = -continuous_action(s, -e.roll_sp, action_y);  // theta_y = -roll
   }
   c.action = action; c.action_y = action_y;
+  c.coin = (r[2] >> 31) != 0; c.coin_y = (r2[2] >> 31) != 0;
   e.action = action | (two ? action_y << 2 : 0);
   return c;
 }
 // End of an agent period: fresh Euler angles, discretise / check / reward (mdp.py:257-541), TD target (double_q_learning.py:136-145)
 template <typename T, typename TabPtr>
-DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, int mode) {
+DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
   StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
   const bool two = s.two_axis != 0;
   const int prev_idx = c.prev_idx, prev_idy = c.prev_idy;
@@ -683,24 +685,43 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
   out.reward_fx = __double2ll_rn((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (two) out.reward_fx += __double2ll_rn((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (mode == MODE_TRAIN) {
-    const double q0 = qa[idx * 3], q1 = qa[idx * 3 + 1], q2 = qa[idx * 3 + 2];
-    const int b = argmax3(q0, q1, q2);
-    const double boot = b == 0 ? q0 : (b == 1 ? q1 : q2);
-    int mask;
-    if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
-    else mask = !done;
-    const double target = (double)rew + (m.gamma * boot) * (double)mask;
-    out.cell = prev_idx * 3 + c.action;
-    out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+    // Reference (B1/B2, DQL_Q_UPDATE_TABLE_A_ONLY): always Q_table_a, valued by itself.  Otherwise Double Q-learning as the paper
+    // has it: the coin picks the table to update, the OTHER table values the picked table's greedy action at s'.
+    const bool dbl = !(s.quirks & DQL_Q_UPDATE_TABLE_A_ONLY);
+    {
+      const bool sel_b = dbl && c.coin;
+      const double a0 = qa[idx * 3], a1 = qa[idx * 3 + 1], a2 = qa[idx * 3 + 2];
+      double s0 = a0, s1 = a1, s2 = a2, v0 = a0, v1 = a1, v2 = a2;
+      if (dbl) {
+        const double b0 = qb[idx * 3], b1 = qb[idx * 3 + 1], b2 = qb[idx * 3 + 2];
+        s0 = sel_b ? b0 : a0; s1 = sel_b ? b1 : a1; s2 = sel_b ? b2 : a2;
+        v0 = sel_b ? a0 : b0; v1 = sel_b ? a1 : b1; v2 = sel_b ? a2 : b2;
+      }
+      const int b = argmax3(s0, s1, s2);
+      const double boot = b == 0 ? v0 : (b == 1 ? v1 : v2);
+      int mask;
+      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
+      else mask = !done;
+      const double target = (double)rew + (m.gamma * boot) * (double)mask;
+      out.cell = prev_idx * 3 + c.action + (sel_b ? DQL_N_CELLS : 0);
+      out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+    }
     if (two) {  // the y transition updates the same shared tables
-      const double y0 = qa[idy * 3], y1 = qa[idy * 3 + 1], y2 = qa[idy * 3 + 2];
-      const int by = argmax3(y0, y1, y2);
-      const double boot_y = by == 0 ? y0 : (by == 1 ? y1 : y2);
+      const bool sel_b = dbl && c.coin_y;
+      const double a0 = qa[idy * 3], a1 = qa[idy * 3 + 1], a2 = qa[idy * 3 + 2];
+      double s0 = a0, s1 = a1, s2 = a2, v0 = a0, v1 = a1, v2 = a2;
+      if (dbl) {
+        const double b0 = qb[idy * 3], b1 = qb[idy * 3 + 1], b2 = qb[idy * 3 + 2];
+        s0 = sel_b ? b0 : a0; s1 = sel_b ? b1 : a1; s2 = sel_b ? b2 : a2;
+        v0 = sel_b ? a0 : b0; v1 = sel_b ? a1 : b1; v2 = sel_b ? a2 : b2;
+      }
+      const int by = argmax3(s0, s1, s2);
+      const double boot_y = by == 0 ? v0 : (by == 1 ? v1 : v2);
       int mask_y;
       if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
       else mask_y = !done;
       const double target_y = (double)rew_y + (m.gamma * boot_y) * (double)mask_y;
-      out.cell_y = prev_idy * 3 + c.action_y;
+      out.cell_y = prev_idy * 3 + c.action_y + (sel_b ? DQL_N_CELLS : 0);
       out.target_y_fx = __double2ll_rn(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
     }
   }
@@ -790,7 +811,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
   }
   DQL_SECTION("epilogue");
   DQL_MARK_T(e, 4);
-  const StepOut o = period_end(s, mp, e, c, qa, mode);
+  const StepOut o = period_end(s, mp, e, c, qa, qb, mode);
   DQL_MARK_T(e, 5);
   return o;
 }

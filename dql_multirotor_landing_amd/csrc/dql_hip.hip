@@ -132,7 +132,12 @@ DQL_DEV double fold_q(const FoldK& f, double q, double cnt, long long Tsum, long
   }
   return tbar + (q - tbar) * shrink;
 }
-// fold one cell of an accumulator pair into the master tables (and the multi-GPU window), clear the accumulator
+// Accumulators are [4][N_CELLS]: Q_table_a's {target sums, visits}, then Q_table_b's (the second pair stays empty under the
+// reference's table-a-only quirk); the visit counter is shared, so table a's fold goes first and table b's visits take the
+// learning rates after it (same order in the oracle).
+#define DQL_ACC_LEN (4 * DQL_N_CELLS)
+#define DQL_ACC_B (2 * DQL_N_CELLS)
+// fold one cell of ONE table's accumulator pair into that master table (and the multi-GPU window), clear the accumulator
 DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long* acc, long long* window, int windowed, int c) {
   const long long Tsum = acc[c], m = acc[DQL_N_CELLS + c];
   double q = qa_m[c];
@@ -154,7 +159,7 @@ template <typename T> struct StepArgs {
   unsigned long long* acc_cur;         // [2][DQL_N_CELLS] of this launch: target sums (fixed point), visits
   // table-writer blocks (blockIdx >= env_blocks): fold launch j-1's accumulators into the master tables while the env blocks
   // run, publish the result as the acting tables of launch j+1 -> the table update costs no kernel and no time of its own
-  double* qa_m; double* cnt_m; double* qa_pub; long long* acc_prev; long long* window;
+  double* qa_m; double* qb_m; double* cnt_m; double* qa_pub; double* qb_pub; long long* acc_prev; long long* window;
   FoldK fold;
   StatsDev* stats;
   const uint8_t* actions;
@@ -209,8 +214,8 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
   constexpr bool STAGED = BLOCK > 64;
-  __shared__ unsigned long long sT[STAGED ? DQL_N_CELLS : 1];
-  __shared__ unsigned int sM[STAGED ? DQL_N_CELLS : 1];
+  __shared__ unsigned long long sT[STAGED ? 2 * DQL_N_CELLS : 1];  // staged index = table * N_CELLS + cell (StepOut::cell)
+  __shared__ unsigned int sM[STAGED ? 2 * DQL_N_CELLS : 1];
   __shared__ unsigned long long sStat[4];
   warm_kernarg<(int)sizeof(StepArgs<T>)>();
   const int tid = threadIdx.x;
@@ -220,15 +225,20 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
   if ((int)blockIdx.x >= a.env_blocks) {  // table-writer block (whole block takes this path: no barrier is skipped)
     const int c = ((int)blockIdx.x - a.env_blocks) * BLOCK + tid;
     if (c < DQL_N_CELLS) {
-      double q = a.qa_m[c];
-      if (a.have_prev) q = fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc_prev, a.window, a.windowed, c);
-      a.qa_pub[c] = q;
+      double qa = a.qa_m[c], qb = a.qb_m[c];
+      if (a.have_prev) {
+        qa = fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc_prev, a.window, a.windowed, c);
+        qb = fold_cell(a.fold, a.qb_m, a.cnt_m, a.acc_prev + DQL_ACC_B, a.window + DQL_ACC_B, a.windowed, c);
+      }
+      a.qa_pub[c] = qa; a.qb_pub[c] = qb;
     }
     return;
   }
   const int ncell = (a.c.working + 1) * DQL_CELLS_PER_LEVEL;
+  const int n_tab = (a.c.quirks & DQL_Q_UPDATE_TABLE_A_ONLY) ? 1 : 2;  // tables that can receive targets (wave-uniform)
   if (STAGED) {
-    for (int c = tid; c < ncell; c += BLOCK) { sT[c] = 0ull; sM[c] = 0u; }
+    for (int t = 0; t < n_tab; ++t)
+      for (int c = tid; c < ncell; c += BLOCK) { sT[t * DQL_N_CELLS + c] = 0ull; sM[t * DQL_N_CELLS + c] = 0u; }
     if (tid < 4) sStat[tid] = 0ull;
     __syncthreads();
   }
@@ -254,8 +264,9 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
       if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
       if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
     } else {  // the atomics go out first: their round trip hides behind the state stores
-      if (o.cell >= 0) { atomicAdd(&a.acc_cur[o.cell], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + o.cell], 1ull); }
-      if (o.cell_y >= 0) { atomicAdd(&a.acc_cur[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + o.cell_y], 1ull); }
+      // global layout [4][N_CELLS]: a staged index in table b's half sits another N_CELLS further on
+      if (o.cell >= 0) { const int g = o.cell + (o.cell >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
+      if (o.cell_y >= 0) { const int g = o.cell_y + (o.cell_y >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
       store_env(e, a.sr, a.si, a.n, i, a.c);
     }
     dec = o.decision; don = o.done; rfx = o.reward_fx;
@@ -281,10 +292,11 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
       if (rfx) atomicAdd(&sStat[2], (unsigned long long)rfx);
     }
     __syncthreads();
-    for (int c = tid; c < ncell; c += BLOCK) {
-      const unsigned int m = sM[c];
-      if (m) { atomicAdd(&a.acc_cur[c], sT[c]); atomicAdd(&a.acc_cur[DQL_N_CELLS + c], (unsigned long long)m); }
-    }
+    for (int t = 0; t < n_tab; ++t)
+      for (int c = tid; c < ncell; c += BLOCK) {
+        const unsigned int m = sM[t * DQL_N_CELLS + c];
+        if (m) { atomicAdd(&a.acc_cur[t * DQL_ACC_B + c], sT[t * DQL_N_CELLS + c]); atomicAdd(&a.acc_cur[t * DQL_ACC_B + DQL_N_CELLS + c], (unsigned long long)m); }
+      }
     if (tid == 0) { dec = (long long)sStat[0]; don = (long long)sStat[1]; rfx = (long long)sStat[2]; }
   }
   if (tid == 0) {
@@ -299,24 +311,31 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
 }
 
 // fold the last launch's accumulators into the master tables outside a launch (host table access, level switch, rank sync)
-struct FlushArgs { double* qa_m; double* cnt_m; long long* acc; long long* window; FoldK fold; int windowed; };
+struct FlushArgs { double* qa_m; double* qb_m; double* cnt_m; long long* acc; long long* window; FoldK fold; int windowed; };
 __global__ void k_flush(FlushArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < DQL_N_CELLS) fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc, a.window, a.windowed, c);
+  if (c < DQL_N_CELLS) {
+    fold_cell(a.fold, a.qa_m, a.cnt_m, a.acc, a.window, a.windowed, c);
+    fold_cell(a.fold, a.qb_m, a.cnt_m, a.acc + DQL_ACC_B, a.window + DQL_ACC_B, a.windowed, c);
+  }
 }
 // multi-GPU: fold the all-reduced window into the base tables; master and both acting buffers restart from the base
-struct WindowArgs { double* qa_base; double* count_base; double* qa_m; double* cnt_m; double* tb0; double* tb1; long long* window; FoldK fold; };
+struct WindowArgs { double* qa_base; double* qb_base; double* count_base; double* qa_m; double* qb_m; double* cnt_m; double* tb0; double* tb1; double* tbb0; double* tbb1; long long* window; FoldK fold; };
 __global__ void k_apply_window(WindowArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= DQL_N_CELLS) return;
-  const long long Tsum = a.window[c], m = a.window[DQL_N_CELLS + c];
-  if (m > 0) {
-    a.qa_base[c] = fold_q(a.fold, a.qa_base[c], a.count_base[c], Tsum, m);
-    a.count_base[c] += (double)m;
-    a.window[c] = 0; a.window[DQL_N_CELLS + c] = 0;
+  for (int t = 0; t < 2; ++t) {  // table a first: the shared counter orders the learning rates
+    long long* w = a.window + t * DQL_ACC_B;
+    double* base = t ? a.qb_base : a.qa_base;
+    const long long Tsum = w[c], m = w[DQL_N_CELLS + c];
+    if (m > 0) {
+      base[c] = fold_q(a.fold, base[c], a.count_base[c], Tsum, m);
+      a.count_base[c] += (double)m;
+      w[c] = 0; w[DQL_N_CELLS + c] = 0;
+    }
   }
-  const double q = a.qa_base[c];
-  a.qa_m[c] = q; a.cnt_m[c] = a.count_base[c]; a.tb0[c] = q; a.tb1[c] = q;
+  const double qa = a.qa_base[c], qb = a.qb_base[c];
+  a.qa_m[c] = qa; a.qb_m[c] = qb; a.cnt_m[c] = a.count_base[c]; a.tb0[c] = qa; a.tb1[c] = qa; a.tbb0[c] = qb; a.tbb1[c] = qb;
 }
 __global__ void k_mark_reset(int4* si, const uint8_t* mask, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,8 +412,9 @@ struct dql_ctx {
   void* sr = nullptr;  // Quad<T>[NQ_REAL][n]
   int4* si = nullptr;
   double *qa = nullptr, *qb = nullptr, *count = nullptr;          // MASTER tables: every accumulator folded except the last launch's (`pending`)
+  double* tbb[2] = {nullptr, nullptr};                            // ... and of Q_table_b (it learns too unless the table-a-only quirk is set)
   double* tb[2] = {nullptr, nullptr};                             // ACTING copies of Q_table_a: launch j reads tb[j & 1], its writer blocks fill tb[(j + 1) & 1]
-  double *qa_base = nullptr, *count_base = nullptr;               // multi-GPU base tables
+  double *qa_base = nullptr, *qb_base = nullptr, *count_base = nullptr;               // multi-GPU base tables
   long long* acc[2] = {nullptr, nullptr};                         // accumulators: launch j adds into acc[j & 1]; its writer blocks fold and clear acc[(j + 1) & 1]
   long long *window = nullptr, *window_own = nullptr;
   double* alpha_tab = nullptr; int n_tab = 0;
@@ -455,8 +475,9 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.c = make_simk<T>(x->cfg);
   a.mdp = (const MdpK<T>*)x->mdpk;
   a.sr = (Quad<T>*)x->sr; a.si = x->si;
-  a.qa = x->tb[j & 1]; a.qb = x->qb; a.acc_cur = (unsigned long long*)x->acc[j & 1];
-  a.qa_m = x->qa; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
+  a.qa = x->tb[j & 1]; a.qb = x->tbb[j & 1]; a.acc_cur = (unsigned long long*)x->acc[j & 1];
+  a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.qb_pub = x->tbb[(j + 1) & 1];
+  a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
   a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->d_actions;
   a.elog = x->elog ? x->elog + (size_t)x->elog_n * 2 * (size_t)((x->n + 63) >> 6) : nullptr;
   a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
@@ -498,7 +519,7 @@ static int launch_period(dql_ctx* x, int mode, double eps) {
 // fold the last launch's accumulators into the master tables now
 static int flush_pending(dql_ctx* x) {
   if (!x->pending) return DQL_OK;
-  FlushArgs f{x->qa, x->count, x->acc[(x->step_index + 1) & 1], x->window, make_foldk(x), x->windowed ? 1 : 0};
+  FlushArgs f{x->qa, x->qb, x->count, x->acc[(x->step_index + 1) & 1], x->window, make_foldk(x), x->windowed ? 1 : 0};
   hipLaunchKernelGGL(k_flush, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, f);
   HIP_TRY(hipGetLastError());
   x->pending = false;
@@ -506,7 +527,10 @@ static int flush_pending(dql_ctx* x) {
 }
 // master -> both acting buffers (after the host or a transfer rewrote the master tables)
 static int publish_master(dql_ctx* x) {
-  for (int k = 0; k < 2; ++k) HIP_TRY(hipMemcpyAsync(x->tb[k], x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(hipMemcpyAsync(x->tb[k], x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+    HIP_TRY(hipMemcpyAsync(x->tbb[k], x->qb, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+  }
   return DQL_OK;
 }
 
@@ -614,16 +638,21 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   ALLOC(x->si, (size_t)x->n * sizeof(int4));
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
   ALLOC(x->qa_base, DQL_N_CELLS * sizeof(double)); ALLOC(x->count_base, DQL_N_CELLS * sizeof(double));
-  for (int k = 0; k < 2; ++k) { ALLOC(x->tb[k], DQL_N_CELLS * sizeof(double)); ALLOC(x->acc[k], 2 * DQL_N_CELLS * sizeof(long long)); }
-  ALLOC(x->window_own, 2 * DQL_N_CELLS * sizeof(long long)); x->window = x->window_own;
+  ALLOC(x->qb_base, DQL_N_CELLS * sizeof(double));
+  for (int k = 0; k < 2; ++k) { ALLOC(x->tb[k], DQL_N_CELLS * sizeof(double)); ALLOC(x->tbb[k], DQL_N_CELLS * sizeof(double)); ALLOC(x->acc[k], DQL_ACC_LEN * sizeof(long long)); }
+  ALLOC(x->window_own, DQL_ACC_LEN * sizeof(long long)); x->window = x->window_own;
   ALLOC(x->stats, sizeof(StatsDev)); ALLOC(x->d_actions, (size_t)x->n); ALLOC(x->mdpk, sizeof(MdpK<double>));
 #undef ALLOC
   HIP_TRY(hipMemsetAsync(x->sr, 0, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size, x->stream));
   HIP_TRY(hipMemsetAsync(x->qa, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->qb, 0, DQL_N_CELLS * sizeof(double), x->stream));
   HIP_TRY(hipMemsetAsync(x->count, 0, DQL_N_CELLS * sizeof(double), x->stream));
   HIP_TRY(hipMemsetAsync(x->qa_base, 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->count_base, 0, DQL_N_CELLS * sizeof(double), x->stream));
-  for (int k = 0; k < 2; ++k) { HIP_TRY(hipMemsetAsync(x->tb[k], 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->acc[k], 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream)); }
-  HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  HIP_TRY(hipMemsetAsync(x->qb_base, 0, DQL_N_CELLS * sizeof(double), x->stream));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(hipMemsetAsync(x->tb[k], 0, DQL_N_CELLS * sizeof(double), x->stream)); HIP_TRY(hipMemsetAsync(x->tbb[k], 0, DQL_N_CELLS * sizeof(double), x->stream));
+    HIP_TRY(hipMemsetAsync(x->acc[k], 0, DQL_ACC_LEN * sizeof(long long), x->stream));
+  }
+  HIP_TRY(hipMemsetAsync(x->window, 0, DQL_ACC_LEN * sizeof(long long), x->stream));
   HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream)); HIP_TRY(hipMemsetAsync(x->d_actions, 2, (size_t)x->n, x->stream));
   rc = upload_mdpk(x);
   if (rc) { dql_destroy(x); return rc; }
@@ -642,7 +671,7 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->qa_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog};
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -843,9 +872,9 @@ int dql_set_tables(dql_ctx* x, const double* qa, const double* qb, const double*
   { int rc = flush_pending(x); if (rc) return rc; }
   const size_t B = DQL_N_CELLS * sizeof(double);
   if (qa) { HIP_TRY(hipMemcpyAsync(x->qa, qa, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->qa_base, qa, B, hipMemcpyHostToDevice, x->stream)); }
-  if (qb) HIP_TRY(hipMemcpyAsync(x->qb, qb, B, hipMemcpyHostToDevice, x->stream));
+  if (qb) { HIP_TRY(hipMemcpyAsync(x->qb, qb, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->qb_base, qb, B, hipMemcpyHostToDevice, x->stream)); }
   if (count) { HIP_TRY(hipMemcpyAsync(x->count, count, B, hipMemcpyHostToDevice, x->stream)); HIP_TRY(hipMemcpyAsync(x->count_base, count, B, hipMemcpyHostToDevice, x->stream)); }
-  if (qa) { int rc = publish_master(x); if (rc) return rc; }
+  if (qa || qb) { int rc = publish_master(x); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }
@@ -858,6 +887,7 @@ int dql_transfer(dql_ctx* x, int32_t k, double ratio) {
   hipLaunchKernelGGL(k_transfer, dim3((DQL_CELLS_PER_LEVEL + 255) / 256), dim3(256), 0, x->stream, x->qa, x->qb, k, src, ratio);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->qb_base, x->qb, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
   return publish_master(x);
 }
 
@@ -874,8 +904,9 @@ int dql_set_windowed(dql_ctx* x, int32_t on) {
   { int rc = flush_pending(x); if (rc) return rc; }
   if (on && !x->windowed) {
     HIP_TRY(hipMemcpyAsync(x->qa_base, x->qa, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+    HIP_TRY(hipMemcpyAsync(x->qb_base, x->qb, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
     HIP_TRY(hipMemcpyAsync(x->count_base, x->count, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
-    HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+    HIP_TRY(hipMemsetAsync(x->window, 0, DQL_ACC_LEN * sizeof(long long), x->stream));
   }
   x->windowed = on != 0;
   return DQL_OK;
@@ -883,7 +914,7 @@ int dql_set_windowed(dql_ctx* x, int32_t on) {
 int dql_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
   CHECK_CTX(x);
   if (dev_ptr) *dev_ptr = x->window;
-  if (n_int64) *n_int64 = 2 * DQL_N_CELLS;
+  if (n_int64) *n_int64 = DQL_ACC_LEN;
   return DQL_OK;
 }
 int dql_set_window_buffer(dql_ctx* x, void* dev_ptr) {
@@ -892,7 +923,7 @@ int dql_set_window_buffer(dql_ctx* x, void* dev_ptr) {
   { int rc = flush_pending(x); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(x->stream));
   x->window = dev_ptr ? (long long*)dev_ptr : x->window_own;
-  HIP_TRY(hipMemsetAsync(x->window, 0, 2 * DQL_N_CELLS * sizeof(long long), x->stream));
+  HIP_TRY(hipMemsetAsync(x->window, 0, DQL_ACC_LEN * sizeof(long long), x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }
@@ -902,7 +933,7 @@ int dql_apply_accum(dql_ctx* x) {
   if (!x->windowed) return fail(DQL_ESTATE, "dql_apply_accum needs windowed accumulation (dql_set_windowed)");
   if (x->pending) return fail(DQL_ESTATE, "dql_apply_accum: call dql_flush before reducing the window (the last launch is not in it yet)");
   HIP_TRY(hipSetDevice(x->device));
-  WindowArgs a{x->qa_base, x->count_base, x->qa, x->count, x->tb[0], x->tb[1], x->window, make_foldk(x)};
+  WindowArgs a{x->qa_base, x->qb_base, x->count_base, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->window, make_foldk(x)};
   hipLaunchKernelGGL(k_apply_window, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, a);
   HIP_TRY(hipGetLastError());
   return DQL_OK;
@@ -911,14 +942,14 @@ int dql_get_accum(dql_ctx* x, int64_t* out) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   { int rc = flush_pending(x); if (rc) return rc; }
-  HIP_TRY(hipMemcpyAsync(out, x->window, 2 * DQL_N_CELLS * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipMemcpyAsync(out, x->window, DQL_ACC_LEN * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }
 int dql_set_accum(dql_ctx* x, const int64_t* in) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
-  HIP_TRY(hipMemcpyAsync(x->window, in, 2 * DQL_N_CELLS * sizeof(long long), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->window, in, DQL_ACC_LEN * sizeof(long long), hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
 }

@@ -1,8 +1,8 @@
 """Multi-GPU exchange: envs shard across ranks with no data-path collective; the only exchange is
-the periodic sum of the int64 window accumulators [2][2835] = {fixed-point TD-target sums, visit counts}, after
+the periodic sum of the int64 window accumulators [4][2835] = {fixed-point TD-target sums, visit counts} of the two tables, after
 which every rank folds the same totals into its base tables (bit-identical replicas, independent of the order of
 summation).  One process per GPU; `torch.distributed` (backend "nccl" = RCCL over xGMI) is plumbing only: it
-owns the 45 KB exchange buffer and runs the all-reduce on the engine's HIP stream.
+owns the 90 KB exchange buffer and runs the all-reduce on the engine's HIP stream.
 
 `ShardedRunner` is backend-agnostic: the engine is anything with train_steps / apply_accum / window access (the HIP
 `Engine` in production; CPU tests inject a stand-in to exercise sharding + reduction with the gloo backend)."""
@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-from .config import N_CELLS
+from .config import ACC_LEN
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -31,7 +31,7 @@ class TorchWindowReducer:
         self.torch, self.dist, self.group = torch, dist, group
         self.engine = engine
         dev = torch.device("cuda", device_index)
-        self.buf = torch.zeros(2 * N_CELLS, dtype=torch.int64, device=dev)
+        self.buf = torch.zeros(ACC_LEN, dtype=torch.int64, device=dev)
         engine.set_window_buffer(self.buf.data_ptr())
         self.stream = torch.cuda.ExternalStream(engine.stream_handle(), device=dev)
 

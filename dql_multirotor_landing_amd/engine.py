@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .config import CHECK_NAMES, DqlConfig, N_CELLS, TABLE_SHAPE
+from .config import ACC_LEN, CHECK_NAMES, DqlConfig, N_CELLS, TABLE_SHAPE
 
 
 def _p(a):
@@ -155,7 +155,7 @@ class Engine:
         _lib.check(self.lib.dql_apply_accum(self._h))
 
     def get_accum(self):
-        a = np.zeros(2 * N_CELLS, dtype=np.int64)
+        a = np.zeros(ACC_LEN, dtype=np.int64)
         _lib.check(self.lib.dql_get_accum(self._h, _p(a)))
         return a
 

@@ -53,11 +53,10 @@ enum {
   DQL_Q_SHAPING_SURVIVES_RESET = 1 << 2,/* B9  pkg/mdp.py:196-197,469-474 */
   DQL_Q_FROZEN_ACC_REFERENCE = 1 << 3,  /* B19 pkg/observation_utils.py:137-150: last_velocity never updated */
   DQL_Q_BOOTSTRAP_ON_POS_CHANGE = 1 << 4,/* B3  pkg/double_q_learning.py:139-145 */
-  DQL_Q_UPDATE_TABLE_A_ONLY = 1 << 5,   /* B1/B2 pkg/double_q_learning.py:101-108,136-146.  Honoured by dql_agent_update (the
-                                         * ordered single-transition operator).  The batched trainer (dql_train_steps) updates
-                                         * Q_table_a only in BOTH modes, as the reference does: Q_table_b changes through
-                                         * dql_set_tables / dql_transfer alone.  True Double Q-learning (coin-picked table, the
-                                         * other table values its greedy action) is not built: DESIGN.md section 10. */
+  DQL_Q_UPDATE_TABLE_A_ONLY = 1 << 5,   /* B1/B2 pkg/double_q_learning.py:101-108,136-146: both arms of the coin pick Q_table_a and
+                                         * it values its own greedy action.  Cleared (mode="paper"): Double Q-learning as the paper
+                                         * has it: a fair coin picks the table to update, the OTHER table values the picked
+                                         * table's greedy action at s'; Q_table_b learns too. */
   DQL_Q_REFERENCE = 0x3f
 };
 
@@ -182,13 +181,14 @@ int dql_get_tables(dql_ctx* ctx, double* qa, double* qb, double* count); /* 2835
 int dql_set_tables(dql_ctx* ctx, const double* qa, const double* qb, const double* count);
 int dql_transfer(dql_ctx* ctx, int32_t k, double ratio); /* transfer_learning (pkg/double_q_learning.py:77-89) */
 
-/* ---- multi-GPU exchange: int64 accumulators [2][2835] = {sum of targets (fixed point), visits} ---- */
+/* ---- multi-GPU exchange: int64 accumulators [4][2835] = Q_table_a's {sum of targets (fixed point), visits},
+ * then Q_table_b's (all zero under DQL_Q_UPDATE_TABLE_A_ONLY) ---- */
 int dql_set_sync_period(dql_ctx* ctx, int32_t k_steps); /* 1 = apply every step (single-GPU semantics) */
 /* windowed accumulation: every step also adds its accumulators into the window buffer and updates only the local
  * work tables; dql_apply_accum folds the (all-reduced) window into the base tables and re-bases the work tables */
 int dql_set_windowed(dql_ctx* ctx, int32_t on);
 int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device buffer to all-reduce (sum) */
-/* use a caller-owned device buffer of 2*2835 int64 as the window (e.g. a torch tensor handed to torch.distributed);
+/* use a caller-owned device buffer of 4*2835 int64 as the window (e.g. a torch tensor handed to torch.distributed);
  * NULL restores the context's own buffer.  The buffer is zeroed; the context never frees it. */
 int dql_set_window_buffer(dql_ctx* ctx, void* dev_ptr);
 int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
@@ -197,7 +197,7 @@ int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
  * call it before all-reducing the window buffer directly. */
 int dql_flush(dql_ctx* ctx);
 int dql_apply_accum(dql_ctx* ctx); /* fold the (all-reduced) window into the base tables; master and acting tables restart from them */
-int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy, for tests */
+int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy of the 4*2835 window words, for tests */
 int dql_set_accum(dql_ctx* ctx, const int64_t* in);
 
 /* ---- stats / timing ---- */

@@ -735,26 +735,39 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   if (two) st->reward_fx += llrint((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (done) { st->episodes += 1; st->by_code[e->code] += 1; }
   if (mode == 0) {
-    /* TD target of _update_q_table (pkg/double_q_learning.py:136-145), accumulated in fixed point */
-    const double* qn = qa + idx * 3;
-    const double boot = qn[argmax3(qn[0], qn[1], qn[2])];
-    int mask = 1;
-    if (s->quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
-    else mask = !done;
-    const double target = (double)rew + (gamma * boot) * (double)mask;
-    const int cell = prev_idx * 3 + action;
-    accum[cell] += llrint(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
-    accum[DQL_N_CELLS + cell] += 1;
+    /* TD target of _update_q_table (pkg/double_q_learning.py:136-145), accumulated in fixed point: accum = [4][N_CELLS] =
+     * {target sums, visits} of Q_table_a, then of Q_table_b.  Reference (B1/B2, DQL_Q_UPDATE_TABLE_A_ONLY): always table a,
+     * valued by itself.  Without the quirk, Double Q-learning as the paper has it: a fair coin (bit 31 of the third word of
+     * the period's action stream; that word places the vehicle in reset periods and is free in all others) picks the table
+     * to update, and the OTHER table values the picked table's greedy action at s'. */
+    const int dbl = !(s->quirks & DQL_Q_UPDATE_TABLE_A_ONLY);
+    {
+      const int sel_b = dbl && (r[2] >> 31);
+      const double* qsel = (sel_b ? qb : qa) + idx * 3;
+      const double* qval = dbl ? (sel_b ? qa : qb) + idx * 3 : qsel;
+      const double boot = qval[argmax3(qsel[0], qsel[1], qsel[2])];
+      int mask = 1;
+      if (s->quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
+      else mask = !done;
+      const double target = (double)rew + (gamma * boot) * (double)mask;
+      const int cell = prev_idx * 3 + action;
+      int64_t* acc = accum + (sel_b ? 2 * DQL_N_CELLS : 0);
+      acc[cell] += llrint(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      acc[DQL_N_CELLS + cell] += 1;
+    }
     if (two) { /* the y transition updates the same shared tables (scripts/simulation.py:15-16 loads one table pair for both axes) */
-      const double* qy = qa + idy * 3;
-      const double boot_y = qy[argmax3(qy[0], qy[1], qy[2])];
+      const int sel_b = dbl && (r2[2] >> 31);
+      const double* qsel = (sel_b ? qb : qa) + idy * 3;
+      const double* qval = dbl ? (sel_b ? qa : qb) + idy * 3 : qsel;
+      const double boot_y = qval[argmax3(qsel[0], qsel[1], qsel[2])];
       int mask_y;
       if (s->quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
       else mask_y = !done;
       const double target_y = (double)rew_y + (gamma * boot_y) * (double)mask_y;
       const int cell_y = prev_idy * 3 + action_y;
-      accum[cell_y] += llrint(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
-      accum[DQL_N_CELLS + cell_y] += 1;
+      int64_t* acc = accum + (sel_b ? 2 * DQL_N_CELLS : 0);
+      acc[cell_y] += llrint(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      acc[DQL_N_CELLS + cell_y] += 1;
     }
   }
 }
@@ -812,14 +825,14 @@ EXPORT void ORC(agent_periods)(const dql_config* c, void* envs_, int64_t n, cons
 #pragma omp parallel num_threads(n_threads) if (n_threads > 1)
   {
     ostats_t st; memset(&st, 0, sizeof(st));
-    int64_t* acc = n_threads > 1 ? (int64_t*)calloc(2 * DQL_N_CELLS, sizeof(int64_t)) : accum;
+    int64_t* acc = n_threads > 1 ? (int64_t*)calloc(4 * DQL_N_CELLS, sizeof(int64_t)) : accum;
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < n; ++i)
       env_agent_period(&s, &m, &envs[i], qa, qb, acc, &st, mode, eps, ext_actions ? ext_actions + i : 0, seed,
                        (uint32_t)(env_id_offset + i), step_index, g0, n_ticks, c->gamma);
 #pragma omp critical
     {
-      if (n_threads > 1) { for (int k = 0; k < 2 * DQL_N_CELLS; ++k) accum[k] += acc[k]; free(acc); }
+      if (n_threads > 1) { for (int k = 0; k < 4 * DQL_N_CELLS; ++k) accum[k] += acc[k]; free(acc); }
       stats_out[0] += st.decisions; stats_out[1] += st.episodes;
       for (int k = 0; k < DQL_N_CHECK_CODES; ++k) stats_out[2 + k] += st.by_code[k];
       stats_out[11] += st.reward_fx;
@@ -959,21 +972,28 @@ EXPORT void orc_transfer(double* qa, double* qb, int k, double ratio, int n_leve
 }
 /* batched table update: for every cell visited m times with mean target tbar,
  *   Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j)),  count += m
- * (m = 1 is the reference's Q += alpha (target - Q)); alpha(c) = alpha_tab[c] for c < n_tab, alpha_min beyond */
-EXPORT void orc_apply_accum(double* qa, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min, int per_step) {
+ * (m = 1 is the reference's Q += alpha (target - Q)); alpha(c) = alpha_tab[c] for c < n_tab, alpha_min beyond.
+ * accum = [4][N_CELLS]: Q_table_a's {sums, visits}, then Q_table_b's; one shared visit counter (state_action_counter,
+ * pkg/double_q_learning.py:100): table a's visits of a launch take the learning rates alpha(c) .. alpha(c + m_a - 1),
+ * table b's the next m_b. */
+EXPORT void orc_apply_accum(double* qa, double* qb, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min, int per_step) {
   for (int cell = 0; cell < DQL_N_CELLS; ++cell) {
-    const int64_t m = accum[DQL_N_CELLS + cell];
-    if (m <= 0) continue;
-    const double tbar = ((double)accum[cell] * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
-    const int64_t c0 = (int64_t)count[cell];
-    double shrink = 1.0; int64_t j = 0;
-    const int64_t m_eff = per_step ? 1 : m;
-    for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
-    int64_t rem = m_eff - j;
-    if (rem > 0) { double base = 1.0 - alpha_min, pw = 1.0; while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; } shrink *= pw; }
-    qa[cell] = tbar + (qa[cell] - tbar) * shrink;
-    count[cell] += (double)m;
-    accum[cell] = 0; accum[DQL_N_CELLS + cell] = 0;
+    for (int t = 0; t < 2; ++t) {
+      int64_t* acc = accum + t * 2 * DQL_N_CELLS;
+      double* q = t ? qb : qa;
+      const int64_t m = acc[DQL_N_CELLS + cell];
+      if (m <= 0) continue;
+      const double tbar = ((double)acc[cell] * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
+      const int64_t c0 = (int64_t)count[cell];
+      double shrink = 1.0; int64_t j = 0;
+      const int64_t m_eff = per_step ? 1 : m;
+      for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
+      int64_t rem = m_eff - j;
+      if (rem > 0) { double base = 1.0 - alpha_min, pw = 1.0; while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; } shrink *= pw; }
+      q[cell] = tbar + (q[cell] - tbar) * shrink;
+      count[cell] += (double)m;
+      acc[cell] = 0; acc[DQL_N_CELLS + cell] = 0;
+    }
   }
 }
 /* physics ticks of agent period j: floor((j+1) T/dt) - floor(j T/dt), T = 1/f_ag */

@@ -68,8 +68,9 @@ class Oracle:
         self._qa = np.zeros(N_CELLS, dtype=np.float64)      # master
         self._count = np.zeros(N_CELLS, dtype=np.float64)
         self.qa_act = np.zeros(N_CELLS, dtype=np.float64)   # acting copy of Q_table_a
-        self.qb = np.zeros(N_CELLS, dtype=np.float64)
-        self.accum = np.zeros(2 * N_CELLS, dtype=np.int64)
+        self._qb = np.zeros(N_CELLS, dtype=np.float64)     # master
+        self.qb_act = np.zeros(N_CELLS, dtype=np.float64)  # acting copy of Q_table_b
+        self.accum = np.zeros(4 * N_CELLS, dtype=np.int64)  # [4][N_CELLS]: table a's {target sums, visits}, then table b's
         self.pending = None
         self.stats = np.zeros(12, dtype=np.int64)
         self.alpha_tab = cfg.alpha_table() if alpha_tab is None else _f64(alpha_tab)
@@ -89,6 +90,11 @@ class Oracle:
         return self._qa
 
     @property
+    def qb(self):
+        self.flush()
+        return self._qb
+
+    @property
     def count(self):
         self.flush()
         return self._count
@@ -100,7 +106,9 @@ class Oracle:
             if self.windowed:
                 self.qa_base[:] = self._qa
         if qb is not None:
-            self.qb[:] = _f64(qb).ravel()
+            self._qb[:] = _f64(qb).ravel(); self.qb_act[:] = self._qb
+            if self.windowed:
+                self.qb_base[:] = self._qb
         if count is not None:
             self._count[:] = _f64(count).ravel()
             if self.windowed:
@@ -130,7 +138,7 @@ class Oracle:
         """New env per level (pkg/trainer.py:172-183): new limits; every env re-enters through reset; the new level acts on
         everything learnt so far."""
         self.flush()
-        self.qa_act[:] = self._qa
+        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
         self.cfg.working_curriculum_step = level
         self.c = self.cfg.to_c()
         reals, ints = self.get_fields()
@@ -138,15 +146,15 @@ class Oracle:
         self.set_fields(reals, ints)
 
     # ---- stepping ----
-    def _contract(self, qa, count, accum):
-        lib().orc_apply_accum(_p(qa), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
+    def _contract(self, qa, qb, count, accum):
+        lib().orc_apply_accum(_p(qa), _p(qb), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
                               C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step))
 
     def _fold_pending(self):
         if self.pending is not None:
             if self.windowed:
                 self.window += self.pending
-            self._contract(self._qa, self._count, self.pending)
+            self._contract(self._qa, self._qb, self._count, self.pending)
             self.pending = None
 
     def flush(self):
@@ -158,7 +166,7 @@ class Oracle:
         g0 = self.cfg.ticks_before(j)
         n_ticks = self.cfg.ticks_before(j + 1) - g0
         act = None if actions is None else np.ascontiguousarray(actions, dtype=np.uint8)
-        self._fn("agent_periods")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), _p(self.qa_act), _p(self.qb), _p(self.accum),
+        self._fn("agent_periods")(C.byref(self.c), _p(self.envs), C.c_int64(self.n), _p(self.qa_act), _p(self.qb_act), _p(self.accum),
                                    _p(self.stats), C.c_int(mode), C.c_double(eps), _p(act) if act is not None else None,
                                    C.c_uint64(self.seed), C.c_int64(self.off), C.c_int64(j), C.c_int64(g0), C.c_int(n_ticks), C.c_int(self.n_threads))
         self.step_index += 1
@@ -175,7 +183,7 @@ class Oracle:
             self._elog.append(row)
         # what the writer workgroups of this launch do meanwhile: fold launch j-1, publish the acting tables of launch j+1
         self._fold_pending()
-        self.qa_act[:] = self._qa
+        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
         if mode == 0:
             self.pending = self.accum.copy()
         self.accum[:] = 0
@@ -184,8 +192,8 @@ class Oracle:
     def set_windowed(self, on: bool):
         self.flush()
         if on and not self.windowed:
-            self.qa_base = self._qa.copy(); self.count_base = self._count.copy()
-            self.window = np.zeros(2 * N_CELLS, dtype=np.int64)
+            self.qa_base = self._qa.copy(); self.qb_base = self._qb.copy(); self.count_base = self._count.copy()
+            self.window = np.zeros(4 * N_CELLS, dtype=np.int64)
         self.windowed = bool(on)
 
     def get_accum(self):
@@ -198,8 +206,9 @@ class Oracle:
     def apply_accum(self):
         """fold the (all-reduced) window into the base tables; master and acting tables restart from the base"""
         assert self.pending is None, "flush before reducing the window"
-        self._contract(self.qa_base, self.count_base, self.window)
-        self._qa[:] = self.qa_base; self._count[:] = self.count_base; self.qa_act[:] = self.qa_base
+        self._contract(self.qa_base, self.qb_base, self.count_base, self.window)
+        self._qa[:] = self.qa_base; self._qb[:] = self.qb_base; self._count[:] = self.count_base
+        self.qa_act[:] = self.qa_base; self.qb_act[:] = self.qb_base
 
     def episode_log_enable(self, capacity_periods: int):
         self._elog = [] if capacity_periods else None
@@ -224,10 +233,10 @@ class Oracle:
 
     def transfer(self, k: int, ratio: float):
         self.flush()
-        lib().orc_transfer(_p(self._qa), _p(self.qb), C.c_int(k), C.c_double(ratio), C.c_int(5))
-        self.qa_act[:] = self._qa
+        lib().orc_transfer(_p(self._qa), _p(self._qb), C.c_int(k), C.c_double(ratio), C.c_int(5))
+        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
         if self.windowed:
-            self.qa_base[:] = self._qa
+            self.qa_base[:] = self._qa; self.qb_base[:] = self._qb
 
     def stats_dict(self):
         s = self.stats

@@ -274,3 +274,27 @@ def test_episode_log_matches_oracle(mods, n, block):
     eng.episode_log_read()
     eng.episode_log_enable(0)
     eng.train_steps(3, 0.2)
+
+
+def test_double_q_learning_updates_both_tables_in_paper_mode(mods):
+    """Without the reference's table-a-only quirk (B1/B2) the coin-picked table learns, valued by the other one (oracle:
+    env_agent_period); with it, Q_table_b never changes.  Both tables and the shared counter bit-exact, windowed too."""
+    Engine, Oracle = mods
+    n = 640
+    for quirks, expect_b in ((Q_PAPER, True), (0x3F, False)):
+        eng = Engine(DqlConfig(dtype=F32, quirks=quirks), n, seed=5)
+        orc = Oracle(DqlConfig(dtype=F32, quirks=quirks), n, seed=5, n_threads=8)
+        eng.train_steps(150, 0.5); orc.train_steps(150, 0.5)
+        _compare(eng, orc, exact=True, what=f"quirks {quirks:#x}")
+        qa, qb, cnt = eng.get_tables()
+        assert (qa != 0).any() and bool((qb != 0).any()) == expect_b
+        if expect_b:  # roughly half of the updates each
+            assert 0.3 < (qb != 0).sum() / max(1, (qa != 0).sum()) < 3.0
+    eng = Engine(DqlConfig(dtype=F32, quirks=Q_PAPER), n, seed=6); eng.set_windowed(True)
+    orc = Oracle(DqlConfig(dtype=F32, quirks=Q_PAPER), n, seed=6, n_threads=8); orc.set_windowed(True)
+    for _ in range(5):
+        eng.train_steps(7, 0.3); orc.train_steps(7, 0.3)
+        acc = eng.get_accum()
+        assert acc.shape == (4 * 2835,) and np.array_equal(acc, orc.get_accum()) and acc[2 * 2835:].any()
+        eng.apply_accum(); orc.flush(); orc.apply_accum()
+        _compare(eng, orc, exact=True, what="windowed double Q")
