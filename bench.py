@@ -68,31 +68,41 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
         from dql_multirotor_landing_amd.config import Q_PAPER
         from dql_multirotor_landing_amd.dist import TorchComm
         from dql_multirotor_landing_amd.trainer import Trainer
-        with tempfile.TemporaryDirectory() as d:
-            comm = TorchComm(None, dev_index) if world > 1 else None
-            # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
-            # generations of all of them, or a level ends before most envs have finished an episode
-            budget = max(args.curriculum_budget, 16 * args.envs * world)
-            tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
-                         max_num_episodes=budget, checkpoint_every=10**9, comm=comm)
-            t0 = time.perf_counter()
-            hist = tr.curriculum_training()
-            total = time.perf_counter() - t0
-            if rank != 0:
-                return None
-            sys.path.insert(0, str(ROOT / "scripts"))
-            import simulation
-            ev = {}
-            for name, tables in (("trained", Path(d) / "run"), ("reference_assets", ROOT / "tests" / "golden" / "assets")):
-                h = simulation.evaluate(tables, 4096, 4, flavour="simulation", quirks=Q_PAPER, device=dev_index)
-                g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
-                ev[name] = {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
-        return {"wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total, "mode": "paper",
+        sys.path.insert(0, str(ROOT / "scripts"))
+        import simulation
+
+        def greedy(tables):
+            h = simulation.evaluate(tables, 4096, 4, flavour="simulation", quirks=Q_PAPER, device=dev_index)
+            g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
+            return {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
+
+        comm = TorchComm(None, dev_index) if world > 1 else None
+        # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
+        # generations of all of them, or a level ends before most envs have finished an episode
+        budget = max(args.curriculum_budget, 16 * args.envs * world)
+        runs = []
+        for seed in (42, 1, 2):  # tabular RL is seed-noisy: three full curricula, each reported
+            with tempfile.TemporaryDirectory() as d:
+                tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
+                             max_num_episodes=budget, checkpoint_every=10**9, comm=comm, seed=seed)
+                t0 = time.perf_counter()
+                hist = tr.curriculum_training()
+                total = time.perf_counter() - t0
+                if rank == 0:
+                    runs.append({"seed": seed, "wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total,
+                                 "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
+                                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
+                                 "stage4_greedy_4096_episodes": greedy(Path(d) / "run")})
+                tr._engine.close()
+        if rank != 0:
+            return None
+        mean = lambda k: sum(r[k] for r in runs) / len(runs)
+        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper (Double Q-learning)",
                 "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2 if world > 1 else 1,
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
-                "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
-                            "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
-                "stage4_greedy_4096_episodes": ev}
+                "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
+                                                "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},
+                "runs": runs}
     except Exception as e:  # noqa: BLE001 - the throughput line must survive
         return {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
 
