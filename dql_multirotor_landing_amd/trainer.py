@@ -4,6 +4,11 @@
 GPU: `Engine.train_steps` is the inner `while not done` body (guess, env.step, agent.update) of every env, and the
 host only evaluates the episode-indexed schedules between chunks of agent periods.
 
+`mode`: "reference" reproduces the reference's behaviour including its quirks (only Q_table_a is
+updated and values itself, transfer after a level with the k = 0 wrap, ...); "paper" is what the code was written to do:
+Double Q-learning (a coin picks the table to update, the other one values its greedy action), quirks B3 / B7 / B8 / B9 / B19
+off, transfer before the new level.
+
 Promotion (`promotion_rule`): "ordered" is the reference's rule itself — a deque of the last 100 episodes, checked after
 every episode — on the episodes of the first `judge_envs` envs, generation by generation: all first episodes of the level
 in env order, then all second ones, ... (promotion.py explains why neither completion nor start order will do; the engine's
