@@ -184,13 +184,18 @@ def main():
     s1 = eng.stats()
     decisions = s1["decisions"] - s0["decisions"]
 
-    # per-launch duration of the fused step kernel, HIP events on the engine's stream (separate short pass)
+    # Average launch duration of the fused step kernel, HIP events on the engine's stream.  One rank: the step kernel is the
+    # only kernel between the two events of the timed region (K launches back to back), so duration = region / K — the figure
+    # rocprofv3's kernel summary of the same command reports (profiles/r1_bench_kernel_stats.csv).  Event PAIRS around single
+    # launches (second figure) add the event records and an idle boundary per launch; with several ranks the timed region also
+    # holds the exchange kernels, so there the pairs are the per-launch figure.
     eng.kernel_timer(True)
     eng.train_steps(min(200, max(20, args.steps // 10)), args.eps)
-    k_ms, k_n = eng.kernel_time_ms()
+    k_pairs_ms, k_n = eng.kernel_time_ms()
     eng.kernel_timer(False)
     s2 = eng.stats()
     dec_per_launch = (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])
+    k_ms = dev_ms / args.steps if world == 1 else k_pairs_ms
 
     curriculum = None
     if not args.no_curriculum and not args.two_axis:
@@ -224,7 +229,8 @@ def main():
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": k_n,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": args.steps if world == 1 else k_n,
+                         "kernel_avg_ms_event_pairs": k_pairs_ms,
                          "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
