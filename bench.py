@@ -79,7 +79,7 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
         comm = TorchComm(None, dev_index) if world > 1 else None
         # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
         # generations of all of them, or a level ends before most envs have finished an episode
-        budget = max(args.curriculum_budget, 16 * args.envs * world)
+        budget = max(args.curriculum_budget, 64 * args.envs * world)
         runs = []
         for seed in (42, 1, 2):  # tabular RL is seed-noisy: three full curricula, each reported
             with tempfile.TemporaryDirectory() as d:
@@ -97,7 +97,7 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
         if rank != 0:
             return None
         mean = lambda k: sum(r[k] for r in runs) / len(runs)
-        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper (Double Q-learning)",
+        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper (Double Q-learning), one learning-rate step per launch (Trainer default)",
                 "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2 if world > 1 else 1,
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
-    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 16 per env")
+    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 64 per env")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -23,9 +23,16 @@ dist.ShardedRunner, the per-chunk counters are all-reduced and the judged envs' 
 env order), so every rank takes the same promotion decisions and the run does not depend on the number of ranks.
 
 Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
-promotion_rule, judge_envs, sync_period, max_steps_per_level, fold_per_step, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
+promotion_rule, judge_envs, sync_period, max_steps_per_level, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
 exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
 generation, so `eps_episode_scale = s` reads the schedule at episodes / s).
+`fold_per_step` (default 1): how a launch's m visits of a table cell move its value.  0: as m sequential visits (the
+contraction over alpha(c) .. alpha(c+m-1)); 1: one learning-rate step towards the launch's mean target.  For one env both
+are the reference's rule (m <= 1).  With thousands of envs a cell collects hundreds of visits per launch and the
+sequential form has no memory left — every launch's batch mean replaces the value, and the policies that come out lose the
+platform in 8–25 % of the episodes (profiles/r1_stage4_many_envs_attempts.jsonl); the per-launch step averages over ~1/alpha
+launches the way the reference averages over visits, needs an episode budget of ~64 per env and level, and lands at the
+reference tables' touchdown rate with fly-zone exits at the infeasible-start floor (profiles/r1_stage4_per_step_fold.jsonl).
 Trainer state is saved as JSON (never pickle); the reference's resume path is broken (B12), this one works."""
 from __future__ import annotations
 
@@ -57,7 +64,7 @@ class Trainer:
                  t_max: int = 20, z_init: float = 4.0, f_ag: float = 22.92, p_max: float = 4.5,
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
-                 fold_per_step: int = 0, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
+                 fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
                  judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, comm=None,
                  reducer_factory=None) -> None:
         np.random.seed(seed)

@@ -21,9 +21,9 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--max-steps-per-level", type=int, default=None)
-    ap.add_argument("--max-episodes", type=int, default=50000)
+    ap.add_argument("--max-episodes", type=int, default=None, help="episodes per level before the next level starts (reference: 50000 for one env; default max(50000, 64 per env))")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--fold-per-step", type=int, default=0)
+    ap.add_argument("--fold-per-step", type=int, default=1, help="1 (default): one learning-rate step per launch towards the mean target; 0: m sequential visits")
     ap.add_argument("--eps-floor", type=float, default=0.0)
     ap.add_argument("--success-rate", type=float, default=0.96, help="promotion threshold (reference: 0.96, pkg/trainer.py:25)")
     ap.add_argument("--promotion-rule", default="ordered", choices=["ordered", "aggregate"])
@@ -49,7 +49,7 @@ if __name__ == "__main__":
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local,
                  promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
                  successive_successful_episodes=a.window,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes if a.max_episodes is not None else max(50000, 64 * a.envs), quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
     hist = tr.curriculum_training()
     if rank == 0:
         print(json.dumps({"history": hist, "save_path": str(tr._save_path), "world": world}, indent=1))

@@ -21,7 +21,7 @@ ap.add_argument("--chunk", type=int, default=64)
 ap.add_argument("--rule", default="ordered")
 ap.add_argument("--eps-floor", type=float, default=0.0)
 ap.add_argument("--seeds", type=int, nargs="+", default=[42])
-ap.add_argument("--fold-per-step", type=int, default=0)
+ap.add_argument("--fold-per-step", type=int, default=1)
 ap.add_argument("--eps-scale", type=float, default=1.0)
 ap.add_argument("--quirks", type=lambda x: int(x, 0), default=None, help="override the mode's quirk bits (e.g. 0x37 = reference minus the frozen acceleration reference)")
 a = ap.parse_args()
