@@ -92,13 +92,6 @@ class PromotionWindow:
         self.episodes += n_done
         return hit
 
-    # large-sample view of the same chunk, for logs
-    @staticmethod
-    def rate(done: np.ndarray, goal: np.ndarray):
-        n = int(np.bitwise_count(np.ascontiguousarray(done, dtype=np.uint64)).sum())
-        g = int(np.bitwise_count(np.ascontiguousarray(goal, dtype=np.uint64)).sum())
-        return n, g
-
 
 class EpisodeOrder:
     """Completion masks of the judged envs -> the episodes' goal flags in the order the deque sees them: every judged env's
