@@ -5,8 +5,11 @@
 
 One "step" = one agent period (1/22.92 s of simulated time: 21-22 physics ticks + MDP + TD update) for every env of
 every rank.  Workload at N=1: BASELINE.json configs[1] — 4096 vectorised envs, x-axis MDP, curriculum step 0, eps 1.0,
-state resident in HBM before the timed region.  N>1 (launched by torch.distributed.run): weak scaling, E envs per GPU,
-env shards with global env ids, int64 accumulator all-reduce (RCCL) every --sync-period steps.
+state resident in HBM before the timed region.  N>1: one process per GPU — started by torch.distributed.run (RANK /
+WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment) or, without a launcher, by this script itself (`--gpus N` spawns N
+child ranks before anything touches a GPU and fails if they cannot each have one); weak scaling, E envs per GPU, env
+shards with global env ids, int64 accumulator all-reduce every --sync-period steps by RCCL inside libdql_hip.so.  No
+PyTorch anywhere in this file.
 `value` counts env-steps = (env, period) pairs in which an action was taken (reset periods are not counted).
 Prints ONE JSON line on rank 0.
 """
@@ -59,14 +62,15 @@ def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
             "single_thread_value": d1 / t1, "single_thread_sample": f"{envs} envs x {steps} agent periods ({d1} env-steps, {t1:.1f} s)"}
 
 
-def curriculum_leg(args, world, rank, dev_index, dtype):
+def curriculum_leg(args, comm, world, rank, dev_index, dtype):
     """Second half of BASELINE.json's metric: wall-clock to curriculum stage 4.  The Trainer's loop (reference promotion rule:
     100-episode deque > 0.96 or the level's episode budget runs out) on the same envs-per-GPU, sharded over the ranks of this
-    job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).  Never fails the bench."""
+    job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).  Same table schedule
+    (sync_period 2, the regime in which the run does not depend on the number of ranks) at any N, one GPU included, so the
+    figures of a scaling sweep are the same run on more hardware.  Never fails the bench."""
     import tempfile
     try:
         from dql_multirotor_landing_amd.config import Q_PAPER
-        from dql_multirotor_landing_amd.dist import TorchComm
         from dql_multirotor_landing_amd.trainer import Trainer
         sys.path.insert(0, str(ROOT / "scripts"))
         import simulation
@@ -76,35 +80,89 @@ def curriculum_leg(args, world, rank, dev_index, dtype):
             g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
             return {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
 
-        comm = TorchComm(None, dev_index) if world > 1 else None
         # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
-        # generations of all of them, or a level ends before most envs have finished an episode
+        # generations of all of them, or a level ends before most envs have finished an episode (Trainer default)
         budget = max(args.curriculum_budget, 64 * args.envs * world)
         runs = []
         for seed in (42, 1, 2):  # tabular RL is seed-noisy: three full curricula, each reported
             with tempfile.TemporaryDirectory() as d:
                 tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
-                             max_num_episodes=budget, checkpoint_every=10**9, comm=comm, seed=seed)
+                             max_num_episodes=budget, checkpoint_every=10**9, comm=comm, seed=seed, **CURRICULUM_KW)
                 t0 = time.perf_counter()
                 hist = tr.curriculum_training()
                 total = time.perf_counter() - t0
                 if rank == 0:
                     runs.append({"seed": seed, "wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total,
+                                 "promoted_levels": sum(1 for h in hist if h["promoted"]),
                                  "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
-                                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"]} for h in hist],
+                                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"], "online_success_rate_at_handover": h["success_rate"]} for h in hist],
                                  "stage4_greedy_4096_episodes": greedy(Path(d) / "run")})
                 tr._engine.close()
         if rank != 0:
             return None
         mean = lambda k: sum(r[k] for r in runs) / len(runs)
         return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper (Double Q-learning), one learning-rate step per launch (Trainer default)",
-                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2 if world > 1 else 1,
+                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2, "trainer_kw": CURRICULUM_KW,
+                "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},
                 "runs": runs}
     except Exception as e:  # noqa: BLE001 - the throughput line must survive
-        return {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+        import traceback
+        return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]} if rank == 0 else None
+
+
+CURRICULUM_KW: dict = {}  # Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line)
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU; this parent never
+    touches the GPU), relay rank 0's JSON line, fail loudly when a rank cannot get its GPU or dies."""
+    import socket
+    import subprocess
+    import tempfile
+    import __graft_entry__ as g
+    g.build_hip()  # compile once here (no GPU involved) instead of N times under the lock
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    n = args.gpus
+    procs, out0 = [], tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        time.sleep(0.1)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:  # the others would wait for the dead rank in the communicator: stop exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: rank {failed[0]} of {n} exited with code {failed[1]}: fewer than {n} ranks ran, no result (needs {n} GPUs, one per rank)", file=sys.stderr)
+        return 1
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    rec = json.loads(lines[-1])
+    if rec.get("n_gpus") != n:
+        print(f"bench.py: asked for {n} GPUs, the ranks report {rec.get('n_gpus')}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
 
 
 def main():
@@ -115,80 +173,101 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eps", type=float, default=1.0)
-    ap.add_argument("--sync-period", type=int, default=32)
+    ap.add_argument("--sync-period", type=int, default=32, help="agent periods between table exchanges of the headline run (N > 1); sync_period 2 is reported next to it")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the multi-rank path on fewer GPUs (host-side exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
     ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 64 per env")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # by torch.distributed.run, or by spawn_ranks below
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if launched else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
 
-    dist = None
-    torch = None
-    if world > 1:
-        # torch first: its bundled HIP runtime (same SONAME as /opt/rocm's) must be the one the process binds
-        import torch
-        import torch.distributed as dist
     import __graft_entry__ as g
     g.build_hip()
+    from dql_multirotor_landing_amd.comm import RcclComm
     from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
-    from dql_multirotor_landing_amd.dist import HostWindowReducer, ShardedRunner, TorchWindowReducer
+    from dql_multirotor_landing_amd.dist import RcclWindowReducer, ShardedRunner
     from dql_multirotor_landing_amd.engine import Engine
 
     dtype = F32 if args.dtype == "f32" else F64
     dev_index = local_rank
+    comm = None
     if world > 1:
-        if args.backend == "gloo":
-            dev_index = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(dev_index)
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        try:
+            comm = RcclComm.from_env(dev_index)  # one GPU per rank or an error: never a silent 1-GPU measurement
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            sys.exit(3)
 
     cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis, per_env_platform=args.randomize_platform,
                     noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
-    eng = Engine(cfg, args.envs, seed=42, device=dev_index if world > 1 else 0, env_id_offset=rank * args.envs)
+    eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
-    reducer = None
-    if world > 1:
-        reducer = TorchWindowReducer(eng, dev_index) if args.backend == "nccl" else HostWindowReducer(eng)
-    runner = ShardedRunner(eng, reducer, sync_period=args.sync_period)
+    reducer = RcclWindowReducer(eng, comm) if world > 1 else None
 
     def barrier():
         eng.sync()
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm:
+            comm.barrier()
+            eng.sync()
 
-    runner.train_steps(args.warmup, args.eps)
-    runner.sync()
-    barrier()
-    s0 = eng.stats()
-    eng.timer_start()
-    t0 = time.perf_counter()
-    runner.train_steps(args.steps, args.eps)
-    runner.sync()
-    dev_ms = eng.timer_stop()
-    barrier()
-    wall = time.perf_counter() - t0
-    s1 = eng.stats()
-    decisions = s1["decisions"] - s0["decisions"]
+    def timed(sync_period, steps, warmup):
+        """W untimed + exactly `steps` timed agent periods, barrier + device sync on both sides, MAX over ranks / SUM of env-steps"""
+        runner = ShardedRunner(eng, reducer, sync_period=sync_period)
+        runner.train_steps(warmup, args.eps)
+        runner.sync()
+        barrier()
+        s0 = eng.stats()
+        eng.timer_start()
+        t0 = time.perf_counter()
+        runner.train_steps(steps, args.eps)
+        runner.sync()
+        dev_ms = eng.timer_stop()
+        barrier()
+        wall = time.perf_counter() - t0
+        s1 = eng.stats()
+        dec = s1["decisions"] - s0["decisions"]
+        if comm:
+            wall = float(comm.all_reduce_max([wall])[0]); dec = int(comm.all_reduce_sum([float(dec)])[0])
+        return wall, dec, dev_ms
+
+    wall, decisions, dev_ms = timed(args.sync_period, args.steps, args.warmup)
+    sync_info = None
+    if world > 1:
+        # the exchange's price: same region without exchanges (one window, folded after the clock stops: NOT a valid training
+        # schedule, a yardstick), and at sync_period 2 (the regime in which the run does not depend on the number of ranks)
+        w_none, d_none, _ = timed(args.steps + args.warmup + 1, args.steps, 0)
+        w_two, d_two, _ = timed(2, args.steps, 0)
+        eng.kernel_timer(True)
+        r2 = ShardedRunner(eng, reducer, sync_period=args.sync_period); r2.train_steps(4 * args.sync_period, args.eps); r2.sync()
+        sync_dev_ms, n_sync = eng.sync_time_ms()
+        eng.kernel_timer(False)
+        sync_info = {"sync_period": args.sync_period, "ms_per_step": wall * 1e3 / args.steps, "ms_per_step_no_exchange": w_none * 1e3 / args.steps,
+                     "sync_ms_per_step": (wall - w_none) * 1e3 / args.steps, "exchange_device_ms": sync_dev_ms, "exchanges_timed": n_sync,
+                     "exchange": "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream",
+                     "sync_period_2": {"value": d_two / w_two, "ms_per_step": w_two * 1e3 / args.steps, "sync_ms_per_step": (w_two - w_none) * 1e3 / args.steps}}
 
     # Average launch duration of the fused step kernel, HIP events on the engine's stream.  One rank: the step kernel is the
     # only kernel between the two events of the timed region (K launches back to back), so duration = region / K — the figure
-    # rocprofv3's kernel summary of the same command reports (profiles/r1_bench_kernel_stats.csv).  Event PAIRS around single
+    # rocprofv3's kernel summary of the same command reports.  Event PAIRS around single
     # launches (second figure) add the event records and an idle boundary per launch; with several ranks the timed region also
     # holds the exchange kernels, so there the pairs are the per-launch figure.
+    s1 = eng.stats()
     eng.kernel_timer(True)
     eng.train_steps(min(200, max(20, args.steps // 10)), args.eps)
     k_pairs_ms, k_n = eng.kernel_time_ms()
@@ -199,23 +278,19 @@ def main():
 
     curriculum = None
     if not args.no_curriculum and not args.two_axis:
-        curriculum = curriculum_leg(args, world, rank, dev_index if world > 1 else 0, dtype)
-
-    if world > 1:
-        t = torch.tensor([wall, float(decisions)], dtype=torch.float64, device=f"cuda:{dev_index}" if args.backend == "nccl" else "cpu")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        wall = float(tmax[0]); decisions = int(tsum[1])
+        curriculum = curriculum_leg(args, comm, world, rank, dev_index, dtype)
 
     if rank == 0:
         value = decisions / wall
         traffic, traffic_note = None, "no committed PMC pass for this envs/block configuration"
-        tf = ROOT / "profiles" / "r1_traffic.json"
-        if tf.exists():
-            t = json.loads(tf.read_text())["configs"].get(str(args.envs))
-            if t:
-                traffic = t["hbm_bytes_per_env"] * dec_per_launch
-                traffic_note = "profiles/r1_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction) x env-steps per launch of this run"
+        for name in ("r2_traffic.json", "r1_traffic.json"):
+            tf = ROOT / "profiles" / name
+            if tf.exists():
+                t = json.loads(tf.read_text())["configs"].get(str(args.envs))
+                if t:
+                    traffic = t["hbm_bytes_per_env"] * dec_per_launch
+                    traffic_note = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction) x env-steps per launch of this run"
+                    break
         algo_b = ALGO_BYTES_PER_ENV_STEP_2AXIS if args.two_axis else ALGO_BYTES_PER_ENV_STEP
         ach = algo_b * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
@@ -225,7 +300,7 @@ def main():
             "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
                                    f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per agent period (env step + table fold in writer workgroups), int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
-                       "parallelism": f"env-shard x{world}", "block": args.block,
+                       "parallelism": f"env-shard x{world}" + (", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)" if world > 1 else ""), "block": args.block,
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
@@ -235,19 +310,12 @@ def main():
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
         }
-        # the roof that actually binds: wave64 f32 VALU instructions through 1024 SIMDs at ~1.9 ns each (tools/micro/valu_rate.hip,
-        # profiles/r1_valu_rate.jsonl), instruction count per env wave from the committed PMC pass
-        pf = ROOT / "profiles" / "r1_pmc_sq_summary.json"
-        if pf.exists() and not args.two_axis and args.dtype == "f32":
-            pm = json.loads(pf.read_text())
-            ref = pm.get(str(args.envs)) or (pm.get("1048576") if args.envs > 262144 else pm.get("4096"))
-            ref_envs = args.envs if str(args.envs) in pm else (1048576 if args.envs > 262144 else 4096)
-            valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64)
-            waves = (args.envs + 63) // 64
-            t_floor = valu_per_wave * 1.9e-9 * max(1.0, waves / 1024.0)  # one wave's stream, or the SIMD's share of all waves
-            out["valu_roofline"] = {"valu_instr_per_env_wave": valu_per_wave, "ns_per_wave64_valu_instr_per_simd": 1.9, "simds": 1024,
-                                    "floor_ms_per_launch": t_floor * 1e3, "frac": t_floor * 1e3 / k_ms if k_ms > 0 else None,
-                                    "note": "informational: the fused step is bound by VALU issue (one wave's instruction stream at small batches, all SIMDs busy at large ones), not by HBM"}
+        if sync_info:
+            out["sync"] = sync_info
+            out["sync_ms_per_step"] = sync_info["sync_ms_per_step"]
+        valu = valu_roofline(args, k_ms)
+        if valu:
+            out["valu_roofline"] = valu
         if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
             # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
             big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis), args.large_envs, seed=42)
@@ -259,11 +327,44 @@ def main():
             big.close()
         if curriculum is not None:
             out["curriculum"] = curriculum
-        if not args.no_cpu_baseline:
+            if "error" not in curriculum:  # the two figures the stage-4 check is read from, at the top level
+                out["promoted_levels"] = curriculum["promoted_levels_per_seed"]
+                out["goal_hold_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["goal_hold_rate"]
+                out["touchdown_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["touchdown_rate"]
+                out["wall_to_stage4_s"] = curriculum["wall_to_stage4_s"]
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    eng.close()
+    if comm:
+        comm.barrier()
+        comm.close()
+
+
+def valu_roofline(args, k_ms):
+    """The roof that actually binds: wave64 f32 VALU instructions through 1024 SIMDs (tools/micro/valu_rate.hip prices one), with
+    the instruction count per env wave from the committed PMC pass."""
+    if args.two_axis or args.dtype != "f32":
+        return None
+    pf = next((ROOT / "profiles" / n for n in ("r2_pmc_sq_summary.json", "r1_pmc_sq_summary.json") if (ROOT / "profiles" / n).exists()), None)
+    if pf is None:
+        return None
+    pm = json.loads(pf.read_text())
+    ref = pm.get(str(args.envs)) or (pm.get("1048576") if args.envs > 262144 else pm.get("4096"))
+    if not ref:
+        return None
+    ref_envs = args.envs if str(args.envs) in pm else (1048576 if args.envs > 262144 else 4096)
+    valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64)
+    waves = (args.envs + 63) // 64
+    out = {"valu_instr_per_env_wave": valu_per_wave, "simds": 1024, "source": f"profiles/{pf.name}"}
+    # two prices per instruction: what tools/micro/valu_rate.hip measures on this chip, and MI355X_MICROARCH.md's table
+    # (v_fma_f32: 2 cycles with >= 2 waves per SIMD, 4 for a lone wave) at 2.4 GHz
+    lone = waves <= 1024
+    for tag, ns in (("measured_micro", 1.9), ("guide_table", (4 if lone else 2) / 2.4)):
+        floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)
+        out[tag] = {"ns_per_wave64_valu_instr_per_simd": ns, "floor_ms_per_launch": floor_s * 1e3, "frac": floor_s * 1e3 / k_ms if k_ms > 0 else None}
+    out["note"] = "informational: the fused step is bound by VALU issue (one wave's instruction stream at small batches, all SIMDs busy at large ones), not by HBM"
+    return out
 
 
 if __name__ == "__main__":

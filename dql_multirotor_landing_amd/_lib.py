@@ -11,7 +11,10 @@ from .config import DqlConfigC, N_CHECK_CODES
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
-OK, EINVAL, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4
+OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
+OP_SUM, OP_MAX = 0, 1
 
 
 class DqlStatsC(C.Structure):
@@ -36,6 +39,7 @@ SYMBOLS = {
     "dql_set_curriculum": (C.c_int, [_vp, _i32]),
     "dql_reset": (C.c_int, [_vp, _vp]),
     "dql_step": (C.c_int, [_vp, _vp]),
+    "dql_step_dev": (C.c_int, [_vp, _vp]),
     "dql_train_steps": (C.c_int, [_vp, _i32, _dbl]),
     "dql_eval_steps": (C.c_int, [_vp, _i32]),
     "dql_get_states": (C.c_int, [_vp, _vp, _vp]),
@@ -61,6 +65,20 @@ SYMBOLS = {
     "dql_apply_accum": (C.c_int, [_vp]),
     "dql_get_accum": (C.c_int, [_vp, _vp]),
     "dql_set_accum": (C.c_int, [_vp, _vp]),
+    "dql_get_step_index": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "dql_set_step_index": (C.c_int, [_vp, _i64]),
+    "dql_publish_tables": (C.c_int, [_vp]),
+    "dql_comm_unique_id": (C.c_int, [_vp]),
+    "dql_comm_create": (C.c_int, [C.c_int, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "dql_comm_destroy": (C.c_int, [_vp]),
+    "dql_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "dql_comm_allreduce_f64": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "dql_comm_allreduce_i64": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "dql_comm_allgather_u64": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "dql_comm_barrier": (C.c_int, [_vp]),
+    "dql_attach_comm": (C.c_int, [_vp, _vp]),
+    "dql_allreduce_window": (C.c_int, [_vp]),
+    "dql_sync_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
     "dql_stats_get": (C.c_int, [_vp, C.POINTER(DqlStatsC)]),
     "dql_stats_reset": (C.c_int, [_vp]),
     "dql_timer_start": (C.c_int, [_vp]),
@@ -74,7 +92,7 @@ SYMBOLS = {
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
-    "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32]),
+    "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp]),
 }
 
 _lib = None
@@ -91,7 +109,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
             fn.restype = res
             fn.argtypes = args
-        if lib.dql_abi_version() != 1:
+        if lib.dql_abi_version() != ABI_VERSION:
             raise RuntimeError("libdql_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1,0 +1,152 @@
+"""`RcclComm`: one rank of a one-process-per-GPU job, over the C ABI's RCCL binding (`dql_comm_*`, include/dql.h).
+
+No PyTorch: `libdql_hip.so` loads librccl itself.  The only thing ranks need out of band is rank 0's 128-byte
+`ncclUniqueId`; it travels through a small file that every rank of the job can name without talking to the others:
+
+    $DQL_COMM_ID_FILE                                     if set (the launcher chooses), else
+    $TMPDIR/dql_comm_<uid>_<ppid>_<parent start>_<MASTER_PORT>_<n>.id
+
+All ranks of a node share their parent (torch.distributed.run's agent, or `bench.py --gpus N` itself), and (pid, start
+time) of a live process is unique, so a file left behind by an earlier job can never be mistaken for this one's; `<n>`
+counts the communicators a process has created (every rank creates them in the same order).  Rank 0 writes the file
+atomically (temp + rename) and removes it when the communicator is closed.
+
+Launch contract (same variables torch.distributed.run exports): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.
+"""
+from __future__ import annotations
+
+import atexit
+import ctypes as C
+import os
+import tempfile
+import time
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+_created = 0          # communicators created by this process so far
+_env_comm = None      # the job's communicator (from_env), shared by everything in this process
+
+
+def _parent_token() -> str:
+    ppid = os.getppid()
+    try:  # field 22 of /proc/<pid>/stat: start time in clock ticks since boot (the command name may contain spaces: split after it)
+        start = Path(f"/proc/{ppid}/stat").read_text().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        start = "0"
+    return f"{ppid}_{start}"
+
+
+def id_file_path(seq: int) -> Path:
+    explicit = os.environ.get("DQL_COMM_ID_FILE")
+    if explicit:
+        return Path(explicit if seq == 0 else f"{explicit}.{seq}")
+    port = os.environ.get("MASTER_PORT", "0")
+    return Path(tempfile.gettempdir()) / f"dql_comm_{os.getuid()}_{_parent_token()}_{port}_{seq}.id"
+
+
+class RcclComm:
+    """A rank's RCCL communicator + the Trainer's control-plane exchanges (per-chunk counters: sum; bench timing: max;
+    judged envs' episode logs: gather in rank order = global env order)."""
+
+    def __init__(self, rank: int, world: int, device: int = 0, timeout_s: float = 600.0):
+        global _created
+        self.lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank must be in 0 .. world-1")
+        n = C.c_int(0)
+        _lib.check(self.lib.dql_device_count(C.byref(n)))
+        if self.device >= n.value:
+            raise RuntimeError(f"rank {self.rank} of {self.world} needs GPU {self.device}, but only {n.value} GPU(s) are visible: one process per GPU, no sharing")
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: bootstrap over loopback (the hostname may not resolve)
+        seq, _created = _created, _created + 1
+        self._id_file = id_file_path(seq)
+        uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if self.rank == 0:
+            _lib.check(self.lib.dql_comm_unique_id(uid))
+            if self.world > 1:
+                tmp = self._id_file.with_suffix(f".{os.getpid()}.tmp")
+                tmp.write_bytes(bytes(uid))
+                os.replace(tmp, self._id_file)
+        else:
+            t0 = time.monotonic()
+            while True:
+                try:
+                    b = self._id_file.read_bytes()
+                    if len(b) == _lib.COMM_ID_BYTES:
+                        break
+                except OSError:
+                    pass
+                if time.monotonic() - t0 > timeout_s:
+                    raise RuntimeError(f"rank {self.rank}: no unique id from rank 0 after {timeout_s:.0f} s ({self._id_file})")
+                time.sleep(0.02)
+            uid = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(b)
+        h = C.c_void_p()
+        _lib.check(self.lib.dql_comm_create(self.device, self.rank, self.world, uid, C.byref(h)))
+        self.handle = h
+        atexit.register(self.close)
+
+    @staticmethod
+    def from_env(device: Optional[int] = None) -> Optional["RcclComm"]:
+        """The job's communicator when this process is one rank of a multi-rank launch (WORLD_SIZE > 1), else None.
+        Created once per process."""
+        global _env_comm
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world < 2:
+            return None
+        if _env_comm is None:
+            rank = int(os.environ["RANK"])
+            dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else int(device)
+            _env_comm = RcclComm(rank, world, dev)
+        return _env_comm
+
+    def close(self):
+        global _env_comm
+        if getattr(self, "handle", None):
+            self.lib.dql_comm_destroy(self.handle)
+            self.handle = None
+            if self.rank == 0 and self.world > 1:
+                try:
+                    self._id_file.unlink()
+                except OSError:
+                    pass
+        if _env_comm is self:
+            _env_comm = None
+
+    # ---- table exchange ----
+    def reducer(self, engine):
+        from .dist import RcclWindowReducer
+        return RcclWindowReducer(engine, self)
+
+    # ---- control plane (host arrays) ----
+    def _reduce(self, v, op):
+        a = np.ascontiguousarray(v, dtype=np.float64).copy()
+        _lib.check(self.lib.dql_comm_allreduce_f64(self.handle, a.ctypes.data_as(C.c_void_p), a.size, op))
+        return a
+
+    def all_reduce_sum(self, v) -> np.ndarray:
+        return self._reduce(v, _lib.OP_SUM)
+
+    def all_reduce_max(self, v) -> np.ndarray:
+        return self._reduce(v, _lib.OP_MAX)
+
+    def all_reduce_sum_i64(self, v) -> np.ndarray:
+        a = np.ascontiguousarray(v, dtype=np.int64).copy()
+        _lib.check(self.lib.dql_comm_allreduce_i64(self.handle, a.ctypes.data_as(C.c_void_p), a.size, _lib.OP_SUM))
+        return a
+
+    def all_gather_masks(self, done: np.ndarray, goal: np.ndarray):
+        """[P, W] uint64 on every rank (same shape) -> [P, world * W], rank order"""
+        loc = np.ascontiguousarray(np.stack([np.asarray(done, dtype=np.uint64), np.asarray(goal, dtype=np.uint64)]))
+        out = np.zeros((self.world,) + loc.shape, dtype=np.uint64)
+        _lib.check(self.lib.dql_comm_allgather_u64(self.handle, loc.ctypes.data_as(C.c_void_p), loc.size, out.ctypes.data_as(C.c_void_p)))
+        full = np.concatenate(list(out), axis=2)
+        return full[0], full[1]
+
+    def barrier(self):
+        _lib.check(self.lib.dql_comm_barrier(self.handle))

@@ -13,6 +13,9 @@
 //   k_apply_window           multi-GPU: folds the all-reduced window accumulators into the base tables.
 //   small stateless kernels  drop-in single-call operators (discretise, mdp transition, predict, ordered update).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed on first use (dql_comm_*)
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -116,13 +119,15 @@ template <typename T> __global__ void k_init(InitArgs<T> a) {
 }
 
 // mean-target contraction of one cell: Q <- tbar + (Q - tbar) * prod_{j<m} (1 - alpha(count + j))
-struct FoldK { const double* alpha_tab; int n_tab; double alpha_min; int per_step; };
+struct FoldK { const double* alpha_tab; int n_tab; double alpha_min; int per_step; long long n_launch; };
 DQL_DEV double fold_q(const FoldK& f, double q, double cnt, long long Tsum, long long m) {
   const double tbar = ((double)Tsum * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
   const long long c0 = (long long)cnt;
   double shrink = 1.0;
   long long j = 0;
-  const long long m_eff = f.per_step ? 1 : m;
+  // per_step: one learning-rate step per launch the accumulators cover (1 for a launch's own fold, the window length for
+  // the multi-GPU window), never more steps than visits
+  const long long m_eff = f.per_step ? (m < f.n_launch ? m : f.n_launch) : m;
   for (; j < m_eff && c0 + j < f.n_tab; ++j) shrink *= (1.0 - f.alpha_tab[c0 + j]);
   long long rem = m_eff - j;
   if (rem > 0) {
@@ -385,16 +390,20 @@ __global__ void k_predict(const double* qa, const double* qb, const int* idx, lo
 }
 // ordered replay of DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146): inherently sequential -> one lane
 __global__ void k_update_seq(double* qa, double* qb, double* count, const int* sa, const int* ns, const double* alpha, double gamma,
-                             const double* reward, long long n, uint32_t quirks) {
+                             const double* reward, long long n, uint32_t quirks, const uint8_t* coin, const uint8_t* done) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const bool dbl = !(quirks & DQL_Q_UPDATE_TABLE_A_ONLY);  // Double Q-learning: coin picks the table, the other one values (B1/B2 off)
   for (long long i = 0; i < n; ++i) {
     count[sa[i]] += 1;
-    const double q0 = qa[ns[i] * 3], q1 = qa[ns[i] * 3 + 1], q2 = qa[ns[i] * 3 + 2];
+    const bool sel_b = dbl && coin[i] != 0;
+    double* qsel = sel_b ? qb : qa;
+    const double* qval = dbl ? (sel_b ? qa : qb) : qa;
+    const double q0 = qsel[ns[i] * 3], q1 = qsel[ns[i] * 3 + 1], q2 = qsel[ns[i] * 3 + 2];
     const int b = argmax3(q0, q1, q2);
-    const double best = b == 0 ? q0 : (b == 1 ? q1 : q2);
-    const int mask = idx_pos(sa[i] / 3) != idx_pos(ns[i]);
-    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qa[sa[i]]);
-    qa[sa[i]] += loss;
+    const double best = qval[ns[i] * 3 + b];
+    const int mask = (quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) ? (idx_pos(sa[i] / 3) != idx_pos(ns[i])) : !done[i];
+    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qsel[sa[i]]);
+    qsel[sa[i]] += loss;
   }
 }
 
@@ -434,6 +443,11 @@ struct dql_ctx {
   int block = 0;  // 0 = auto
   unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
   int elog_cap = 0, elog_n = 0;
+  uint8_t* d_mask = nullptr;     // reset mask staging (dql_reset), allocated on first use
+  const uint8_t* ext_actions = nullptr;  // caller-owned device actions of the next external step (dql_step_dev), else d_actions
+  long long window_launches = 0; // training launches whose accumulators the window holds (windowed mode)
+  struct dql_comm* comm = nullptr;  // attached RCCL communicator (not owned)
+  std::vector<hipEvent_t> sev;   // event pairs around the exchanges while the kernel timer is armed
 };
 
 static int check_config(const dql_config* c) {
@@ -443,6 +457,8 @@ static int check_config(const dql_config* c) {
   if (c->pid_vz[2] != 0.0 || c->pid_yaw[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported by the fused kernel (reference launch files use Kd = 0)");
   if (c->manager_div < 1 || c->dt <= 0 || c->f_ag <= 0) return fail(DQL_EINVAL, "dt, f_ag, manager_div must be positive");
   if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
+  // step_count and curriculum_check are packed into 16 bits each (store_env): an episode must time out before they wrap
+  if (!(c->t_max > 0) || c->t_max * c->f_ag >= 65535.0) return fail(DQL_EINVAL, "t_max * f_ag must be in (0, 65535): the per-env step counters are 16 bits wide");
   return DQL_OK;
 }
 
@@ -466,7 +482,7 @@ template <typename T> static int launch_init(dql_ctx* x) {
   return DQL_OK;
 }
 
-static FoldK make_foldk(const dql_ctx* x) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step}; }
+static FoldK make_foldk(const dql_ctx* x, long long n_launch = 1) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step, n_launch}; }
 static long long ticks_before(const dql_ctx* x, long long j) { return (long long)std::floor((double)j * (1.0 / (x->cfg.f_ag * x->cfg.dt))); }
 
 template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, double eps, int envs_per_block) {
@@ -478,7 +494,7 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.qa = x->tb[j & 1]; a.qb = x->tbb[j & 1]; a.acc_cur = (unsigned long long*)x->acc[j & 1];
   a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.qb_pub = x->tbb[(j + 1) & 1];
   a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
-  a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->d_actions;
+  a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->ext_actions ? x->ext_actions : x->d_actions;
   a.elog = x->elog ? x->elog + (size_t)x->elog_n * 2 * (size_t)((x->n + 63) >> 6) : nullptr;
   a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
   a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_ticks = (int)(ticks_before(x, j + 1) - a.g0);
@@ -512,6 +528,7 @@ static int launch_period(dql_ctx* x, int mode, double eps) {
   HIP_TRY(hipGetLastError());
   if (x->elog) x->elog_n += 1;
   x->pending = (mode == MODE_TRAIN);  // this launch's accumulators wait for the next launch's writer blocks (or a flush)
+  if (x->windowed && mode == MODE_TRAIN) x->window_launches += 1;
   x->step_index += 1;
   x->timer_launches += 1;
   return DQL_OK;
@@ -617,21 +634,9 @@ int dql_config_default(dql_config* c) {
   return DQL_OK;
 }
 
-int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed, int64_t env_id_offset, dql_ctx** out) {
-  if (!out) return fail(DQL_EINVAL, "null out pointer");
-  *out = nullptr;
-  int rc = check_config(cfg);
-  if (rc) return rc;
-  if (n_envs < 1 || n_envs > (1ll << 31)) return fail(DQL_EINVAL, "n_envs must be in 1..2^31");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev < 1) return fail(DQL_EHIP, "no HIP device visible: libdql_hip needs an MI355X (there is no CPU fallback)");
-  if (device < 0 || device >= ndev) return fail(DQL_EINVAL, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
-  dql_ctx* x = new dql_ctx();
-  x->cfg = *cfg; x->device = device; x->n = n_envs; x->seed = seed; x->env_id_offset = env_id_offset; x->dtype = cfg->dtype;
-  x->real_size = cfg->dtype == DQL_F32 ? 4 : 8;
-#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { dql_destroy(x); return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } } while (0)
+// allocation + initialisation of a fresh context; any failure leaves a partly built context for the caller to destroy
+static int create_impl(dql_ctx* x, const dql_config* cfg) {
+#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } while (0)
   HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&x->ev0)); HIP_TRY(hipEventCreate(&x->ev1));
   ALLOC(x->sr, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size);
@@ -654,14 +659,36 @@ int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed,
   }
   HIP_TRY(hipMemsetAsync(x->window, 0, DQL_ACC_LEN * sizeof(long long), x->stream));
   HIP_TRY(hipMemsetAsync(x->stats, 0, sizeof(StatsDev), x->stream)); HIP_TRY(hipMemsetAsync(x->d_actions, 2, (size_t)x->n, x->stream));
-  rc = upload_mdpk(x);
-  if (rc) { dql_destroy(x); return rc; }
+  int rc = upload_mdpk(x);
+  if (rc) return rc;
   rc = (x->dtype == DQL_F32) ? launch_init<float>(x) : launch_init<double>(x);
-  if (rc) { dql_destroy(x); return rc; }
+  if (rc) return rc;
   // default alpha table (plateau only): callers install the reference schedule with dql_set_alpha_table
   const double a0 = cfg->alpha_min;
-  rc = dql_set_alpha_table(x, &a0, 1);
-  if (rc) { dql_destroy(x); return rc; }
+  return dql_set_alpha_table(x, &a0, 1);
+}
+
+int dql_create(const dql_config* cfg, int device, int64_t n_envs, uint64_t seed, int64_t env_id_offset, dql_ctx** out) {
+  if (!out) return fail(DQL_EINVAL, "null out pointer");
+  *out = nullptr;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (n_envs < 1 || n_envs > (1ll << 31)) return fail(DQL_EINVAL, "n_envs must be in 1..2^31");
+  if (env_id_offset < 0 || env_id_offset + n_envs > (1ll << 32)) return fail(DQL_EINVAL, "global env ids (env_id_offset .. env_id_offset + n_envs) must fit 32 bits: they key the per-env RNG");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(DQL_EHIP, "no HIP device visible: libdql_hip needs an MI355X (there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(DQL_EINVAL, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  dql_ctx* x = new dql_ctx();
+  x->cfg = *cfg; x->device = device; x->n = n_envs; x->seed = seed; x->env_id_offset = env_id_offset; x->dtype = cfg->dtype;
+  x->real_size = cfg->dtype == DQL_F32 ? 4 : 8;
+  rc = create_impl(x, cfg);
+  if (rc) {
+    const std::string why = g_err;  // dql_destroy must not lose the reason
+    dql_destroy(x);
+    return fail(rc, why);
+  }
   *out = x;
   return DQL_OK;
 }
@@ -671,7 +698,8 @@ int dql_destroy(dql_ctx* x) {
   (void)hipSetDevice(x->device);
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog};
+  for (hipEvent_t e : x->sev) (void)hipEventDestroy(e);
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog, x->d_mask};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -681,9 +709,10 @@ int dql_destroy(dql_ctx* x) {
 }
 
 int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipStreamSynchronize(x->stream)); return DQL_OK; }
-int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); *n = x->n; return DQL_OK; }
+int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); if (!n) return fail(DQL_EINVAL, "null pointer"); *n = x->n; return DQL_OK; }
 int dql_state_bytes_per_env(dql_ctx* x, int64_t* bytes) {
   CHECK_CTX(x);
+  if (!bytes) return fail(DQL_EINVAL, "null pointer");
   // x-axis: quads 0-10 read + written, quads 14-15 written, int4 read + written; two-axis: + quads 11-12
   const int rw = x->cfg.two_axis ? 13 : 11;
   *bytes = (int64_t)((rw + rw + 2) * 4 * x->real_size + 2 * sizeof(int4));
@@ -722,14 +751,15 @@ int dql_set_curriculum(dql_ctx* x, int32_t k) {
 int dql_reset(dql_ctx* x, const uint8_t* mask) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
-  uint8_t* dmask = nullptr;
+  const uint8_t* dmask = nullptr;
   if (mask) {
-    HIP_TRY(hipMalloc((void**)&dmask, (size_t)x->n));
-    HIP_TRY(hipMemcpyAsync(dmask, mask, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+    if (!x->d_mask && hipMalloc((void**)&x->d_mask, (size_t)x->n) != hipSuccess) { x->d_mask = nullptr; return fail(DQL_ENOMEM, "hipMalloc(reset mask) failed"); }
+    HIP_TRY(hipMemcpyAsync(x->d_mask, mask, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));  // the caller's buffer may be reused right after return
+    dmask = x->d_mask;
   }
-  hipLaunchKernelGGL(k_mark_reset, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, x->stream, x->si, (const uint8_t*)dmask, (long long)x->n);
+  hipLaunchKernelGGL(k_mark_reset, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, x->stream, x->si, dmask, (long long)x->n);
   HIP_TRY(hipGetLastError());
-  if (dmask) { HIP_TRY(hipStreamSynchronize(x->stream)); HIP_TRY(hipFree(dmask)); }
   return DQL_OK;
 }
 
@@ -744,7 +774,17 @@ int dql_step(dql_ctx* x, const uint8_t* actions) {
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipMemcpyAsync(x->d_actions, actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));  // the caller's buffer may be reused right after return
+  x->ext_actions = nullptr;
   return launch_period(x, MODE_EXTERNAL, 0.0);
+}
+int dql_step_dev(dql_ctx* x, const uint8_t* dev_actions) {
+  CHECK_CTX(x);
+  if (!dev_actions) return fail(DQL_EINVAL, "dev_actions must not be null");
+  HIP_TRY(hipSetDevice(x->device));
+  x->ext_actions = dev_actions;
+  const int rc = launch_period(x, MODE_EXTERNAL, 0.0);
+  x->ext_actions = nullptr;
+  return rc;
 }
 int dql_train_steps(dql_ctx* x, int32_t n_steps, double eps) {
   CHECK_CTX(x);
@@ -815,6 +855,12 @@ int dql_set_sim_ints(dql_ctx* x, const int32_t* in, int32_t nf) {
   const int n_states = DQL_N_CELLS / DQL_N_ACTIONS;
   for (long long i = 0; i < n; ++i)  // the state indices address the tables on the device: -1 (no state yet) .. 944
     if (in[i] < -1 || in[i] >= n_states || in[n + i] < -1 || in[n + i] >= n_states) return fail(DQL_EINVAL, "idx_x / idx_y out of range (-1 .. 944)");
+  for (long long i = 0; i < n; ++i) {  // code indexes the terminal histogram; the packed counters are 16 bits, the action two 2-bit fields
+    const int32_t sc = in[2 * n + i], cc = in[3 * n + i], code = in[4 * n + i], fl = in[5 * n + i], act = in[6 * n + i];
+    if (code < 0 || code >= DQL_N_CHECK_CODES) return fail(DQL_EINVAL, "code out of range (0 .. 8)");
+    if (sc < 0 || sc > 0xffff || cc < 0 || cc > 0xffff || fl < 0 || fl > 0xff) return fail(DQL_EINVAL, "step_count / cur_check / flags out of range");
+    if (act < 0 || (act & 3) > 2 || ((act >> 2) & 3) > 2 || (act >> 4)) return fail(DQL_EINVAL, "action out of range (ax | ay << 2, ax, ay in 0..2)");
+  }
   std::vector<int4> h((size_t)n);
   for (long long i = 0; i < n; ++i)
     h[i] = make_int4(in[0 * n + i], in[1 * n + i], (in[2 * n + i] & 0xffff) | (in[3 * n + i] << 16),
@@ -907,6 +953,7 @@ int dql_set_windowed(dql_ctx* x, int32_t on) {
     HIP_TRY(hipMemcpyAsync(x->qb_base, x->qb, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
     HIP_TRY(hipMemcpyAsync(x->count_base, x->count, DQL_N_CELLS * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
     HIP_TRY(hipMemsetAsync(x->window, 0, DQL_ACC_LEN * sizeof(long long), x->stream));
+    x->window_launches = 0;
   }
   x->windowed = on != 0;
   return DQL_OK;
@@ -933,9 +980,15 @@ int dql_apply_accum(dql_ctx* x) {
   if (!x->windowed) return fail(DQL_ESTATE, "dql_apply_accum needs windowed accumulation (dql_set_windowed)");
   if (x->pending) return fail(DQL_ESTATE, "dql_apply_accum: call dql_flush before reducing the window (the last launch is not in it yet)");
   HIP_TRY(hipSetDevice(x->device));
-  WindowArgs a{x->qa_base, x->qb_base, x->count_base, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->window, make_foldk(x)};
+  WindowArgs a{x->qa_base, x->qb_base, x->count_base, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->window,
+               make_foldk(x, x->window_launches > 0 ? x->window_launches : 1)};
   hipLaunchKernelGGL(k_apply_window, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, a);
   HIP_TRY(hipGetLastError());
+  x->window_launches = 0;
+  if (x->kernel_timer && (x->sev.size() & 1)) {  // closes the pair dql_allreduce_window opened
+    hipEvent_t e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e1, x->stream)); x->sev.push_back(e1);
+  }
   return DQL_OK;
 }
 int dql_get_accum(dql_ctx* x, int64_t* out) {
@@ -952,6 +1005,25 @@ int dql_set_accum(dql_ctx* x, const int64_t* in) {
   HIP_TRY(hipMemcpyAsync(x->window, in, DQL_ACC_LEN * sizeof(long long), hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return DQL_OK;
+}
+
+int dql_get_step_index(dql_ctx* x, int64_t* step_index) { CHECK_CTX(x); if (!step_index) return fail(DQL_EINVAL, "null pointer"); *step_index = x->step_index; return DQL_OK; }
+int dql_set_step_index(dql_ctx* x, int64_t step_index) {
+  CHECK_CTX(x);
+  if (step_index < 0) return fail(DQL_EINVAL, "step_index must be >= 0");
+  HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
+  // the ping-pong buffers are indexed by the parity of step_index: republish so that either parity reads the same tables
+  { int rc = publish_master(x); if (rc) return rc; }
+  x->stats_step_base += step_index - x->step_index;  // agent_steps since the last stats reset stays what it was
+  x->step_index = step_index;
+  return DQL_OK;
+}
+int dql_publish_tables(dql_ctx* x) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }
+  return publish_master(x);
 }
 
 // ---- stats / timing / knobs ----
@@ -996,6 +1068,8 @@ int dql_kernel_timer(dql_ctx* x, int32_t on) {
   CHECK_CTX(x);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
   x->kev.clear();
+  for (hipEvent_t e : x->sev) (void)hipEventDestroy(e);
+  x->sev.clear();
   x->kernel_timer = on != 0;
   return DQL_OK;
 }
@@ -1007,6 +1081,16 @@ int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
   for (size_t i = 0; i + 1 < x->kev.size(); i += 2) { float f = 0; HIP_TRY(hipEventElapsedTime(&f, x->kev[i], x->kev[i + 1])); tot += f; ++n; }
   if (avg_ms) *avg_ms = n ? tot / (double)n : 0.0;
   if (launches) *launches = n;
+  return DQL_OK;
+}
+int dql_sync_time_ms(dql_ctx* x, double* avg_ms, int64_t* syncs) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  double tot = 0; int64_t n = 0;
+  for (size_t i = 0; i + 1 < x->sev.size(); i += 2) { float f = 0; HIP_TRY(hipEventElapsedTime(&f, x->sev[i], x->sev[i + 1])); tot += f; ++n; }
+  if (avg_ms) *avg_ms = n ? tot / (double)n : 0.0;
+  if (syncs) *syncs = n;
   return DQL_OK;
 }
 int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
@@ -1134,17 +1218,191 @@ int dql_agent_predict(int device, const double* qa, const double* qb, const int3
 }
 
 int dql_agent_update(int device, double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma,
-                     const double* reward, int64_t n, uint32_t quirks) {
+                     const double* reward, int64_t n, uint32_t quirks, const uint8_t* coin, const uint8_t* done) {
   if (n < 0 || !qa || !qb || !count || (n > 0 && (!sa || !ns || !alpha || !reward))) return fail(DQL_EINVAL, "null array");
   if (n == 0) return DQL_OK;
+  if (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && !coin) return fail(DQL_EINVAL, "Double Q-learning (DQL_Q_UPDATE_TABLE_A_ONLY cleared) needs the caller's coin per transition");
+  if (!(quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) && !done) return fail(DQL_EINVAL, "bootstrapping on non-terminal transitions (DQL_Q_BOOTSTRAP_ON_POS_CHANGE cleared) needs the done flags");
   for (int64_t i = 0; i < n; ++i) if (sa[i] < 0 || sa[i] >= DQL_N_CELLS || ns[i] < 0 || ns[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "index out of range");
   OP_PROLOGUE(device)
-  DevBuf a, b, c, s, t, al, rw;
+  DevBuf a, b, c, s, t, al, rw, cn, dn;
   const size_t B = DQL_N_CELLS * sizeof(double);
   UP(a, qa, B); UP(b, qb, B); UP(c, count, B); UP(s, sa, (size_t)n * sizeof(int)); UP(t, ns, (size_t)n * sizeof(int)); UP(al, alpha, (size_t)n * sizeof(double)); UP(rw, reward, (size_t)n * sizeof(double));
-  hipLaunchKernelGGL(k_update_seq, dim3(1), dim3(64), 0, 0, (double*)a.p, (double*)b.p, (double*)c.p, (const int*)s.p, (const int*)t.p, (const double*)al.p, gamma, (const double*)rw.p, (long long)n, quirks);
+  if (coin) UP(cn, coin, (size_t)n);
+  if (done) UP(dn, done, (size_t)n);
+  hipLaunchKernelGGL(k_update_seq, dim3(1), dim3(64), 0, 0, (double*)a.p, (double*)b.p, (double*)c.p, (const int*)s.p, (const int*)t.p, (const double*)al.p, gamma, (const double*)rw.p, (long long)n, quirks,
+                     (const uint8_t*)cn.p, (const uint8_t*)dn.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(qa, a.p, B, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(qb, b.p, B, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(count, c.p, B, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// RCCL communicator.  librccl.so is half a gigabyte: it is loaded with dlopen the first time a
+// communicator is asked for, so a single-GPU process never maps it.
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+  if (g_rccl.handle) return DQL_OK;
+  const char* env = getenv("DQL_RCCL_PATH");
+  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  std::string tried;
+  for (const char* nm : names) {
+    if (!nm || !*nm) continue;
+    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+    tried += std::string(" ") + nm + " (" + dlerror() + ")";
+  }
+  if (!h) return fail(DQL_ERCCL, "cannot load librccl:" + tried);
+#define DQL_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) { dlclose(h); return fail(DQL_ERCCL, std::string("librccl lacks ") + name); } } while (0)
+  DQL_SYM(GetUniqueId, "ncclGetUniqueId"); DQL_SYM(CommInitRank, "ncclCommInitRank"); DQL_SYM(CommDestroy, "ncclCommDestroy");
+  DQL_SYM(AllReduce, "ncclAllReduce"); DQL_SYM(AllGather, "ncclAllGather"); DQL_SYM(GetErrorString, "ncclGetErrorString");
+#undef DQL_SYM
+  g_rccl.handle = h;
+  return DQL_OK;
+}
+#define NCCL_TRY(expr)                                                                                         \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess) return fail(DQL_ERCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(_r));      \
+  } while (0)
+
+struct dql_comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  hipStream_t stream = nullptr;
+  void* stage = nullptr;  // device staging of the host-buffer collectives
+  size_t stage_bytes = 0;
+};
+static int comm_stage(dql_comm* c, size_t bytes) {
+  if (bytes <= c->stage_bytes) return DQL_OK;
+  if (c->stage) { HIP_TRY(hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  if (hipMalloc(&c->stage, bytes) != hipSuccess) { c->stage = nullptr; return fail(DQL_ENOMEM, "hipMalloc(comm staging) failed"); }
+  c->stage_bytes = bytes;
+  return DQL_OK;
+}
+#define CHECK_COMM(c) do { if (!(c)) return fail(DQL_EINVAL, "null communicator"); } while (0)
+
+extern "C" {
+
+int dql_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return fail(DQL_EINVAL, "null pointer");
+  static_assert(sizeof(ncclUniqueId) == DQL_COMM_ID_BYTES, "DQL_COMM_ID_BYTES must be the size of ncclUniqueId");
+  { int rc = load_rccl(); if (rc) return rc; }
+  ncclUniqueId id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return DQL_OK;
+}
+int dql_comm_create(int device, int32_t rank, int32_t world, const uint8_t* id, dql_comm** out) {
+  if (!out) return fail(DQL_EINVAL, "null out pointer");
+  *out = nullptr;
+  if (!id) return fail(DQL_EINVAL, "null unique id");
+  if (world < 1 || rank < 0 || rank >= world) return fail(DQL_EINVAL, "rank must be in 0 .. world-1");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(DQL_EHIP, "no HIP device visible (there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(DQL_EINVAL, "device index out of range");
+  { int rc = load_rccl(); if (rc) return rc; }
+  HIP_TRY(hipSetDevice(device));
+  dql_comm* c = new dql_comm();
+  c->device = device; c->rank = rank; c->world = world;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  int rc = DQL_OK;
+  do {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(DQL_EHIP, "hipStreamCreate failed"); break; }
+    const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+    if (r != ncclSuccess) { c->nccl = nullptr; rc = fail(DQL_ERCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); break; }
+  } while (0);
+  if (rc) { const std::string why = g_err; dql_comm_destroy(c); return fail(rc, why); }
+  *out = c;
+  return DQL_OK;
+}
+int dql_comm_destroy(dql_comm* c) {
+  if (!c) return DQL_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->stage) (void)hipFree(c->stage);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return DQL_OK;
+}
+int dql_comm_info(dql_comm* c, int32_t* rank, int32_t* world, int32_t* device) {
+  CHECK_COMM(c);
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (device) *device = c->device;
+  return DQL_OK;
+}
+static int comm_allreduce(dql_comm* c, void* inout, int64_t n, ncclDataType_t dt, int32_t op) {
+  CHECK_COMM(c);
+  if (n < 0 || (n > 0 && !inout)) return fail(DQL_EINVAL, "null array");
+  if (op != DQL_OP_SUM && op != DQL_OP_MAX) return fail(DQL_EINVAL, "op must be DQL_OP_SUM or DQL_OP_MAX");
+  if (n == 0) return DQL_OK;
+  const size_t bytes = (size_t)n * 8;
+  HIP_TRY(hipSetDevice(c->device));
+  { int rc = comm_stage(c, bytes); if (rc) return rc; }
+  HIP_TRY(hipMemcpyAsync(c->stage, inout, bytes, hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(g_rccl.AllReduce(c->stage, c->stage, (size_t)n, dt, op == DQL_OP_SUM ? ncclSum : ncclMax, c->nccl, c->stream));
+  HIP_TRY(hipMemcpyAsync(inout, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DQL_OK;
+}
+int dql_comm_allreduce_f64(dql_comm* c, double* inout, int64_t n, int32_t op) { return comm_allreduce(c, inout, n, ncclDouble, op); }
+int dql_comm_allreduce_i64(dql_comm* c, int64_t* inout, int64_t n, int32_t op) { return comm_allreduce(c, inout, n, ncclInt64, op); }
+int dql_comm_allgather_u64(dql_comm* c, const uint64_t* in, int64_t n, uint64_t* out) {
+  CHECK_COMM(c);
+  if (n < 0 || (n > 0 && (!in || !out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  const size_t bytes = (size_t)n * 8;
+  HIP_TRY(hipSetDevice(c->device));
+  { int rc = comm_stage(c, bytes * (size_t)(c->world + 1)); if (rc) return rc; }
+  char* send = (char*)c->stage;
+  char* recv = send + bytes;
+  HIP_TRY(hipMemcpyAsync(send, in, bytes, hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(g_rccl.AllGather(send, recv, (size_t)n, ncclUint64, c->nccl, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DQL_OK;
+}
+int dql_comm_barrier(dql_comm* c) {
+  int64_t one = 1;
+  return dql_comm_allreduce_i64(c, &one, 1, DQL_OP_SUM);
+}
+
+int dql_attach_comm(dql_ctx* x, dql_comm* c) {
+  CHECK_CTX(x);
+  if (c && c->device != x->device) return fail(DQL_EINVAL, "communicator and context live on different devices");
+  x->comm = c;
+  return DQL_OK;
+}
+int dql_allreduce_window(dql_ctx* x) {
+  CHECK_CTX(x);
+  if (!x->comm) return fail(DQL_ESTATE, "dql_allreduce_window: no communicator attached (dql_attach_comm)");
+  if (!x->windowed) return fail(DQL_ESTATE, "dql_allreduce_window needs windowed accumulation (dql_set_windowed)");
+  HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }  // the last launch's accumulators enter the window here
+  if (x->kernel_timer) {
+    if (x->sev.size() & 1) { (void)hipEventDestroy(x->sev.back()); x->sev.pop_back(); }  // an exchange that was never folded
+    hipEvent_t e0 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, x->stream)); x->sev.push_back(e0);
+  }
+  NCCL_TRY(g_rccl.AllReduce(x->window, x->window, (size_t)DQL_ACC_LEN, ncclInt64, ncclSum, x->comm->nccl, x->stream));
   return DQL_OK;
 }
 

@@ -11,7 +11,7 @@ from typing import Tuple, Union
 import numpy as np
 
 from . import ops
-from .config import MAX_LEVELS, Q_REFERENCE, TABLE_SHAPE
+from .config import MAX_LEVELS, Q_PAPER, Q_REFERENCE, TABLE_SHAPE
 from .mdp import pack_state
 
 State = Tuple[int, int, int, int, int]
@@ -23,9 +23,16 @@ ASSETS_PATH = Path(__file__).resolve().parent.parent / "assets"  # the reference
 class DoubleQLearningAgent:
     """Agent that learns and makes decisions (two (S,3,3,3,7,3) float64 tables + visit counter)."""
 
-    def __init__(self, curriculum_steps: int = 5, device: int = 0) -> None:
+    def __init__(self, curriculum_steps: int = 5, device: int = 0, mode: str = "reference") -> None:
+        """`mode` (build-specific): "reference" reproduces the reference's update (B1-B3: always Q_table_a, valued by itself,
+        bootstrap only when the position bin changed); "paper" is Double Q-learning as the code was meant to be: the uniform
+        draw of `update` picks the table, the other one values its greedy action, and the bootstrap stops at terminal
+        transitions (`update(..., done=...)`)."""
         if not 1 <= curriculum_steps <= MAX_LEVELS:
             raise ValueError(f"curriculum_steps must be in 1..{MAX_LEVELS}")
+        if mode not in ("reference", "paper"):
+            raise ValueError("mode must be 'reference' or 'paper'")
+        self.mode = mode
         self.curriculum_steps = curriculum_steps
         shape = (curriculum_steps,) + TABLE_SHAPE[1:]
         self.Q_table_a = np.zeros(shape)
@@ -95,13 +102,17 @@ class DoubleQLearningAgent:
         self._unpad(qa, qb, cnt)
 
     # ---- pkg/double_q_learning.py:91-108, 126-146 ----
-    def update(self, current_state_action: StateAction, next_state: State, alpha: float, gamma: float, reward):
+    def update(self, current_state_action: StateAction, next_state: State, alpha: float, gamma: float, reward, done: bool = False):
         sa = self._check_state(current_state_action, 6)
         ns = self._check_state(next_state, 5)
-        np.random.uniform(0, 1)  # drawn and ignored: both arms select Q_table_a (B1)
+        u = np.random.uniform(0, 1)  # reference: drawn and ignored, both arms select Q_table_a (B1); paper mode: the coin
         qa, qb, cnt = self._padded()
-        ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
-                         quirks=Q_REFERENCE, device=self._device)
+        if self.mode == "reference":
+            ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
+                             quirks=Q_REFERENCE, device=self._device)
+        else:
+            ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
+                             quirks=Q_PAPER, device=self._device, coin=[0 if u < 0.5 else 1], done=[1 if done else 0])
         self._unpad(qa, qb, cnt)
 
     # ---- pkg/double_q_learning.py:110-124 ----

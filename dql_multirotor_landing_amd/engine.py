@@ -56,6 +56,10 @@ class Engine:
             raise ValueError("actions must be ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold)")
         _lib.check(self.lib.dql_step(self._h, _p(a)))
 
+    def step_dev(self, dev_ptr: int):
+        """one agent step with actions that already live in device memory (n uint8, e.g. written by the caller's own policy kernel)"""
+        _lib.check(self.lib.dql_step_dev(self._h, C.c_void_p(int(dev_ptr))))
+
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _lib.check(self.lib.dql_reset(self._h, _p(m)))
@@ -162,6 +166,30 @@ class Engine:
     def set_accum(self, a):
         a = np.ascontiguousarray(a, dtype=np.int64)
         _lib.check(self.lib.dql_set_accum(self._h, _p(a)))
+
+    def attach_comm(self, comm_handle):
+        """comm_handle: the dql_comm* of comm.RcclComm (None detaches)"""
+        _lib.check(self.lib.dql_attach_comm(self._h, comm_handle))
+
+    def allreduce_window(self):
+        _lib.check(self.lib.dql_allreduce_window(self._h))
+
+    def sync_time_ms(self):
+        ms = C.c_double(); n = C.c_int64()
+        _lib.check(self.lib.dql_sync_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- checkpoint / resume ----
+    def step_index(self) -> int:
+        v = C.c_int64()
+        _lib.check(self.lib.dql_get_step_index(self._h, C.byref(v)))
+        return v.value
+
+    def set_step_index(self, j: int):
+        _lib.check(self.lib.dql_set_step_index(self._h, int(j)))
+
+    def publish_tables(self):
+        _lib.check(self.lib.dql_publish_tables(self._h))
 
     # ---- stats / timing / knobs ----
     def stats(self):

@@ -63,11 +63,20 @@ def agent_predict(qa, qb, idx, device: int = 0) -> np.ndarray:
     return out
 
 
-def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks: int = Q_REFERENCE, device: int = 0):
-    """In-place ordered replay of DoubleQLearningAgent.update; qa/qb/count must be contiguous float64 of 2835 cells."""
+def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks: int = Q_REFERENCE, device: int = 0, coin=None, done=None):
+    """In-place ordered replay of DoubleQLearningAgent.update; qa/qb/count must be contiguous float64 of 2835 cells.
+    `quirks`: Q_REFERENCE reproduces the reference (table a only, bootstrap on a position-bin change); with
+    Q_UPDATE_TABLE_A_ONLY cleared it is Double Q-learning and needs `coin` (0 = update table a, 1 = table b) per transition,
+    with Q_BOOTSTRAP_ON_POS_CHANGE cleared it needs the `done` flags (include/dql.h)."""
     for t in (qa, qb, count):
         if t.dtype != np.float64 or not t.flags.c_contiguous or t.size != 2835:
             raise ValueError("tables must be contiguous float64 arrays of 2835 cells")
     sa = np.ascontiguousarray(sa, dtype=np.int32); ns = np.ascontiguousarray(ns, dtype=np.int32)
     alpha = _f64(alpha); reward = _f64(reward)
-    _lib.check(_lib.load().dql_agent_update(device, _p(qa), _p(qb), _p(count), _p(sa), _p(ns), _p(alpha), float(gamma), _p(reward), len(sa), quirks))
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    coin, done = u8(coin), u8(done)
+    for a in (coin, done):
+        if a is not None and a.shape != sa.shape:
+            raise ValueError("coin / done must have one entry per transition")
+    _lib.check(_lib.load().dql_agent_update(device, _p(qa), _p(qb), _p(count), _p(sa), _p(ns), _p(alpha), float(gamma), _p(reward), len(sa), quirks,
+                                            None if coin is None else _p(coin), None if done is None else _p(done)))

@@ -65,6 +65,13 @@ class PromotionWindow:
         self._carry = np.arange(-k, 0, dtype=np.int64)  # the entries "before the first episode" count as failures
         self.episodes = 0
 
+    def get_state(self):
+        return {"carry": [int(v) for v in self._carry], "episodes": int(self.episodes)}
+
+    def set_state(self, st):
+        self._carry = np.asarray(st["carry"], dtype=np.int64)
+        self.episodes = int(st["episodes"])
+
     def push_flags(self, flags: np.ndarray):
         """Feed an ordered 0/1 stream (1 = goal state reached).  Returns None or the index (0-based since the last reset) of the
         first episode at which the reference's test passes."""
@@ -107,6 +114,15 @@ class EpisodeOrder:
         """level switch: every env re-enters through reset and starts counting its episodes again"""
         self.count = np.zeros(self.n_cols, dtype=np.int64)  # episodes each env has finished at this level
         self._po = np.zeros(0, dtype=np.int64); self._pe = np.zeros(0, dtype=np.int64); self._pg = np.zeros(0, dtype=bool)
+
+    def get_state(self):
+        return {"count": [int(v) for v in self.count], "po": [int(v) for v in self._po], "pe": [int(v) for v in self._pe],
+                "pg": [int(v) for v in self._pg]}
+
+    def set_state(self, st):
+        self.count = np.asarray(st["count"], dtype=np.int64)
+        self._po = np.asarray(st["po"], dtype=np.int64); self._pe = np.asarray(st["pe"], dtype=np.int64)
+        self._pg = np.asarray(st["pg"], dtype=bool)
 
     @staticmethod
     def _bits(m):

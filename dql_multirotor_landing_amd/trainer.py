@@ -17,15 +17,21 @@ episode log supplies what is needed); "aggregate" is the stricter large-sample f
 the reference (:187, the `for` over `max_num_episodes` simply ends), a level whose episode budget runs out without a
 promotion still hands over to the next level.
 
-Multi-GPU (BASELINE config 4): when `torch.distributed` is initialised with world size > 1 every rank runs
-this same loop on its shard of the `n_envs` global envs; tables synchronise every `sync_period` agent periods through
-dist.ShardedRunner, the per-chunk counters are all-reduced and the judged envs' episode logs all-gathered (rank order = global
-env order), so every rank takes the same promotion decisions and the run does not depend on the number of ranks.
+Multi-GPU (BASELINE config 4): launched as one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in
+the environment, e.g. by torch.distributed.run or `bench.py --gpus N`) every rank runs this same loop on its shard of the
+`n_envs` global envs; tables synchronise every `sync_period` agent periods through dist.ShardedRunner (RCCL all-reduce issued
+by libdql_hip.so, comm.py), the per-chunk counters are all-reduced and the judged envs' episode logs all-gathered (rank order
+= global env order), so every rank takes the same promotion decisions.  What is invariant: for a given `sync_period` the run
+does not depend on the number of ranks — one rank included: `sync_period=S` on a single GPU follows the same windowed table
+schedule (exchange = identity) as 8 GPUs with `sync_period=S`, bit for bit for S <= 2 and per schedule beyond.
+`sync_period=None` (default) means: no windows on one rank (tables act one period late), 2 on several.
 
 Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
 promotion_rule, judge_envs, sync_period, max_steps_per_level, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
 exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
-generation, so `eps_episode_scale = s` reads the schedule at episodes / s).
+generation, so `eps_episode_scale = s` reads the schedule at episodes / s), checkpoint_env_state.
+`max_num_episodes=None` (default) is the reference's 50 000 per level, but at least 64 per env: the reference's figure is
+sized for one env, and a level has to see a few generations of every env.
 `fold_per_step` (default 1): how a launch's m visits of a table cell move its value.  0: as m sequential visits (the
 contraction over alpha(c) .. alpha(c+m-1)); 1: one learning-rate step towards the launch's mean target.  For one env both
 are the reference's rule (m <= 1).  With thousands of envs a cell collects hundreds of visits per launch and the
@@ -33,7 +39,12 @@ sequential form has no memory left — every launch's batch mean replaces the va
 platform in 8–25 % of the episodes (profiles/r1_stage4_many_envs_attempts.jsonl); the per-launch step averages over ~1/alpha
 launches the way the reference averages over visits, needs an episode budget of ~64 per env and level, and lands at the
 reference tables' touchdown rate with fly-zone exits at the infeasible-start floor (profiles/r1_stage4_per_step_fold.jsonl).
-Trainer state is saved as JSON (never pickle); the reference's resume path is broken (B12), this one works."""
+
+Checkpoints: trainer state as JSON (never pickle) + the three `.npy` tables in the reference's layout + (with
+`checkpoint_env_state`) every env's simulator state, the engine's period index and the promotion bookkeeping, so that
+`Trainer.load(dir).curriculum_training()` continues the interrupted level where it stopped — same history and tables as the
+uninterrupted run with the same checkpoint schedule (a checkpoint is a table barrier: pending updates are folded and the acting
+tables refreshed, in both).  The reference's resume path is broken (B12)."""
 from __future__ import annotations
 
 import csv
@@ -47,26 +58,36 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
-from .config import DqlConfig, F32, Q_PAPER, Q_REFERENCE
-from .dist import ShardedRunner, TorchComm, shard_range
+from .comm import RcclComm
+from .config import CHECK_NAMES, DqlConfig, F32, Q_PAPER, Q_REFERENCE
+from .dist import LocalWindowReducer, ShardedRunner, shard_range
 from .double_q_learning import ASSETS_PATH, DoubleQLearningAgent, StateAction
 from .engine import Engine
 from .promotion import EpisodeOrder, PromotionWindow
 
 _TS = r"%d-%m-%Y %H:%M:%S"
+_TERMINAL = CHECK_NAMES[:7]
+# scalar tags of the reference's SummaryWriter (pkg/trainer.py:252-279), one CSV row per chunk of agent periods
+LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode", "Agent periods", "Episode/Success Rate", "Episode/Cumulative Reward",
+                "Episode/Exploration Rate", "Episode/Learning Rate", "Episode/Mean reward"]
+               + [f"Episode/Termination Condition/{c}" for c in _TERMINAL])
+
+# constructor keywords that are not in the reference; saved in trainer.json and restored by load()
+_BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
+               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state")
 
 
 class Trainer:
     def __init__(self, curriculum_steps: int = 5, double_q_learning_agent: Optional[DoubleQLearningAgent] = None,
-                 successive_successful_episodes: int = 100, success_rate: float = 0.96, max_num_episodes: int = 50000,
+                 successive_successful_episodes: int = 100, success_rate: float = 0.96, max_num_episodes: Optional[int] = None,
                  initial_curriculum_step: int = 0, seed: int = 42, save_path=None, *, alpha_min: float = 0.02949, omega: float = 0.51,
                  gamma: float = 0.99, scale_modification_value=(0.8172650252856599, 0.8211253690681617, 0.8257273369742982, 0.8311571820651724),
                  t_max: int = 20, z_init: float = 4.0, f_ag: float = 22.92, p_max: float = 4.5,
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
-                 fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: int = 1,
-                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, comm=None,
-                 reducer_factory=None) -> None:
+                 fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
+                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
+                 comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -83,7 +104,6 @@ class Trainer:
         self._alpha = self._alpha_min
         self._exploration_rate = 0.0
         self._z_init, self._t_max, self._f_ag, self._p_max = z_init, t_max, f_ag, p_max
-        self._max_num_episodes = max_num_episodes
         self._save_path: Path = Path(save_path) if save_path is not None else ASSETS_PATH / datetime.now().strftime(_TS)
         self._seed = seed
         self._current_episode = 0
@@ -92,19 +112,27 @@ class Trainer:
         self._successes = deque([], maxlen=successive_successful_episodes)
         # build-specific
         self._n_envs, self._device, self._dtype, self._mode = int(n_envs), device, dtype, mode
+        # the reference's 50 000 episodes per level are sized for ONE env; N envs need a few generations each
+        self._max_num_episodes = max(50000, 64 * self._n_envs) if max_num_episodes is None else int(max_num_episodes)
         self._chunk_steps, self._checkpoint_every, self._quiet = int(chunk_steps), int(checkpoint_every), quiet
         self._max_steps_per_level = max_steps_per_level
         self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
-        self._promotion_rule, self._sync_period = promotion_rule, int(sync_period)
+        self._promotion_rule = promotion_rule
+        self._sync_period = None if sync_period is None else int(sync_period)
         self._eps_episode_scale = float(eps_episode_scale)
         self._quirks = (Q_REFERENCE if mode == "reference" else Q_PAPER) if quirks is None else int(quirks)
+        self._judge_envs_arg = judge_envs
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
-        self._comm = comm if comm is not None else TorchComm.from_env(device)  # None: single process
+        self._checkpoint_env_state = bool(checkpoint_env_state)
+        self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
         self._reducer_factory = reducer_factory
         self._rank = self._comm.rank if self._comm else 0
         self._world = self._comm.world if self._comm else 1
         self.history = []  # one record per finished curriculum level
         self._engine: Optional[Engine] = None
+        self._progress: Optional[Dict[str, Any]] = None  # bookkeeping of the level in flight (what a checkpoint has to carry)
+        self._resume: Optional[Dict[str, Any]] = None    # set by load(): progress to continue from
+        self._alpha_cum = None
 
     # ---- schedules: pkg/trainer.py:88-138 ----
     def alpha(self, current_state_action: StateAction):
@@ -135,17 +163,31 @@ class Trainer:
 
     # ---- checkpoints: pkg/trainer.py:140-167 (same .npy names, run dir + copy one level up) ----
     def _state_dict(self):
+        build = {k: getattr(self, "_" + k) for k in _BUILD_KEYS if k != "judge_envs"}
+        build["judge_envs"] = self._judge_envs_arg
         return {"curriculum_steps": self._curriculum_steps, "working_curriculum_step": self._working_curriculum_step,
                 "current_episode": self._current_episode, "curriculum_episode_count": self._curriculum_episode_count,
                 "seed": self._seed, "alpha_min": self._alpha_min, "omega": self._omega, "gamma": self._gamma,
                 "scale_modification_value": self._scale_modification_value, "t_max": self._t_max, "z_init": self._z_init,
                 "f_ag": self._f_ag, "p_max": self._p_max, "success_rate": self._success_rate,
                 "successive_successful_episodes": self._successive_successful_episodes, "max_num_episodes": self._max_num_episodes,
-                "n_envs": self._n_envs, "mode": self._mode, "history": self.history}
+                "build": build, "world": self._world, "history": self.history, "progress": self._progress}
+
+    def _env_state_file(self, rank: int) -> Path:
+        return self._save_path / f"env_state_rank{rank}.npz"
 
     def save(self) -> None:
+        eng = self._engine
+        if eng is not None and hasattr(eng, "publish_tables"):
+            eng.publish_tables()  # checkpoint = table barrier: pending updates folded, acting tables = master tables (a resumed run starts so)
         self._pull_tables()
-        if self._rank != 0:  # replicas are identical after a sync: rank 0 writes
+        if eng is not None and self._checkpoint_env_state and self._progress is not None and hasattr(eng, "get_fields"):
+            # every rank writes its own shard: simulator state of every env + the period index the RNG and tick schedule hang on
+            self._save_path.mkdir(parents=True, exist_ok=True)
+            reals, ints = eng.get_fields()
+            np.savez(self._env_state_file(self._rank), reals=reals.astype(np.float32 if self._dtype == F32 else np.float64), ints=ints,
+                     step_index=np.int64(eng.step_index()))
+        if self._rank != 0:  # table replicas are identical after a sync: rank 0 writes
             return
         self._save_path.mkdir(parents=True, exist_ok=True)
         with open(self._save_path / "trainer.json", "w") as f:
@@ -155,6 +197,8 @@ class Trainer:
 
     @staticmethod
     def load(assets_path: Path = ASSETS_PATH, **kw) -> "Trainer":
+        """Latest run directory (named `dd-mm-YYYY HH:MM:SS`, pkg/utils.py) under `assets_path`.  Keywords override what the
+        checkpoint holds (e.g. device=...)."""
         assets_path = Path(assets_path)
         runs = []
         for p in assets_path.iterdir():
@@ -168,12 +212,17 @@ class Trainer:
         with open(run / "trainer.json") as f:
             st = json.load(f)
         agent = DoubleQLearningAgent.load(run)
+        build = dict(st.get("build", {"n_envs": st.get("n_envs", 4096), "mode": st.get("mode", "reference")}))
+        build.update(kw)
         tr = Trainer(curriculum_steps=st["curriculum_steps"], double_q_learning_agent=agent, initial_curriculum_step=st["working_curriculum_step"],
                      seed=st["seed"], save_path=run, alpha_min=st["alpha_min"], omega=st["omega"], gamma=st["gamma"],
                      scale_modification_value=st["scale_modification_value"], t_max=st["t_max"], z_init=st["z_init"], f_ag=st["f_ag"],
                      p_max=st["p_max"], success_rate=st["success_rate"], successive_successful_episodes=st["successive_successful_episodes"],
-                     max_num_episodes=st["max_num_episodes"], n_envs=kw.pop("n_envs", st["n_envs"]), mode=st["mode"], **kw)
+                     max_num_episodes=st["max_num_episodes"], **build)
         tr._current_episode, tr._curriculum_episode_count, tr.history = st["current_episode"], st["curriculum_episode_count"], st["history"]
+        tr._resume = st.get("progress")
+        if tr._resume is not None and st.get("world", 1) != tr._world:
+            raise ValueError(f"checkpoint was written by {st.get('world', 1)} rank(s), this job has {tr._world}: env shards would not line up")
         return tr
 
     # ---- device plumbing ----
@@ -191,23 +240,31 @@ class Trainer:
         if self._engine is None:
             return
         qa, qb, cnt = self._engine.get_tables()
-        self._double_q_learning_agent._unpad(qa.reshape(-1), qb.reshape(-1), cnt.reshape(-1))
+        self._double_q_learning_agent._unpad(np.asarray(qa).reshape(-1), np.asarray(qb).reshape(-1), np.asarray(cnt).reshape(-1))
 
     # ---- pkg/trainer.py:169-245 ----
     def _make_engine(self, cfg):
-        if self._world > 1 or self._reducer_factory is not None:
-            if self._chunk_steps % self._sync_period:
+        sync = self._sync_period if self._sync_period is not None else (2 if self._world > 1 else None)
+        if self._world > 1 or self._reducer_factory is not None or sync is not None:
+            if self._chunk_steps % sync:
                 raise ValueError("chunk_steps must be a multiple of sync_period (checkpoints and promotions happen on synchronised tables)")
             lo, hi = shard_range(self._n_envs, self._rank, self._world)
             eng = Engine(cfg, hi - lo, seed=self._seed, device=self._device, env_id_offset=lo)
-            make = self._reducer_factory if self._reducer_factory is not None else self._comm.reducer
-            return eng, ShardedRunner(eng, make(eng), self._sync_period)
+            if self._reducer_factory is not None:
+                make = self._reducer_factory
+            elif self._world > 1:
+                make = self._comm.reducer
+            else:
+                make = LocalWindowReducer  # one rank on the windowed schedule: what N ranks with this sync period do
+            return eng, ShardedRunner(eng, make(eng), sync)
         eng = Engine(cfg, self._n_envs, seed=self._seed, device=self._device)
         return eng, ShardedRunner(eng, None)
 
     def _chunk_counters(self, s, s_prev):
-        v = np.array([s["episodes"] - s_prev["episodes"], s["by_code"]["TERMINAL_SUCCESS"] - s_prev["by_code"]["TERMINAL_SUCCESS"],  # "Goal state reached" only (B17)
-                      s["decisions"] - s_prev["decisions"], s["reward_sum"] - s_prev["reward_sum"]], dtype=np.float64)
+        by, by0 = s["by_code"], s_prev["by_code"]
+        v = np.array([s["episodes"] - s_prev["episodes"], by["TERMINAL_SUCCESS"] - by0["TERMINAL_SUCCESS"],  # "Goal state reached" only (B17)
+                      s["decisions"] - s_prev["decisions"], s["reward_sum"] - s_prev["reward_sum"]]
+                     + [by.get(c, 0) - by0.get(c, 0) for c in _TERMINAL], dtype=np.float64)
         return self._comm.all_reduce_sum(v) if self._comm else v
 
     def _judge_layout(self):
@@ -231,8 +288,36 @@ class Trainer:
             return self._comm.all_gather_masks(out[0], out[1])
         return out[0], out[1]
 
+    def _mean_alpha(self, cnt_before, cnt_after):
+        """Visit-weighted mean learning rate of the visits between two snapshots of state_action_counter: visit number c of a cell
+        (0-based) is made at alpha(c) (pkg/trainer.py:88-110, B5)."""
+        if self._alpha_cum is None:
+            tab = self._config(0).alpha_table()
+            self._alpha_cum = np.concatenate([[0.0], np.cumsum(tab)])
+        cum, n_tab = self._alpha_cum, len(self._alpha_cum) - 1
+        def total(c):  # sum of alpha(0 .. c-1)
+            c = np.asarray(c, dtype=np.float64)
+            inside = np.minimum(c, n_tab).astype(np.int64)
+            return cum[inside] + (c - inside) * self._alpha_min
+        visits = float(np.sum(cnt_after) - np.sum(cnt_before))
+        if visits <= 0:
+            return self._alpha
+        return float((np.sum(total(cnt_after)) - np.sum(total(cnt_before))) / visits)
+
+    def _restore_env_state(self, eng):
+        f = self._env_state_file(self._rank)
+        if not (self._checkpoint_env_state and f.exists() and hasattr(eng, "set_fields")):
+            return False
+        z = np.load(f, allow_pickle=False)
+        if z["ints"].shape[1] != eng.n:
+            raise ValueError(f"{f} holds {z['ints'].shape[1]} envs, this rank's shard has {eng.n}")
+        eng.set_fields(z["reals"].astype(np.float64), z["ints"])
+        eng.set_step_index(int(z["step_index"]))
+        return True
+
     def curriculum_training(self):
         t_start = time.perf_counter()
+        resume, self._resume = self._resume, None
         cfg = self._config(self._working_curriculum_step)
         self._engine, runner = self._make_engine(cfg)
         self._push_tables()
@@ -243,28 +328,41 @@ class Trainer:
         pw = PromotionWindow(self._successive_successful_episodes, self._success_rate)
         j_cnt, j_w, j_valid = self._judge_layout()
         order = EpisodeOrder(j_valid.size, j_valid)
+        first_level = self._working_curriculum_step
         for self._working_curriculum_step in range(self._working_curriculum_step, self._curriculum_steps):
             k = self._working_curriculum_step
-            if self._mode == "paper" and k >= 1:
-                eng.transfer(k, self.transfer_learning_ratio(k))  # Eq. 31 as intended: the new level starts from the previous one
-            eng.set_curriculum(k)  # "Create a new environment to update limits" (:175-183)
+            resumed = resume is not None and k == first_level and resume.get("level") == k
+            if resumed:
+                # continue the interrupted level: no transfer (it was applied when the level started), tables as checkpointed
+                have_envs = self._restore_env_state(eng)
+                if not have_envs:
+                    eng.set_curriculum(k)  # no simulator state saved: the level's envs start over, its bookkeeping does not
+                pr = resume
+                window = deque(tuple(w) for w in pr["window"])
+                pw.reset(); order.reset()
+                if have_envs:
+                    pw.set_state(pr["pw"]); order.set_state(pr["order"])
+                episodes, steps, chunk_i = int(pr["episodes"]), int(pr["steps"]), int(pr["chunk_i"])
+            else:
+                if self._mode == "paper" and k >= 1:
+                    eng.transfer(k, self.transfer_learning_ratio(k))  # Eq. 31 as intended: the new level starts from the previous one
+                eng.set_curriculum(k)  # "Create a new environment to update limits" (:175-183)
+                window = deque()  # aggregate rule: (episodes, goal-state successes) per chunk, trimmed to the most recent >= 100 episodes
+                pw.reset(); order.reset()
+                episodes, steps, chunk_i = 0, 0, 0
             s_prev = eng.stats()
+            cnt_prev = np.asarray(eng.get_tables()[2], dtype=np.float64).copy()
             t_level = time.perf_counter()
-            window = deque()  # aggregate rule: (episodes, goal-state successes) per chunk, trimmed to the most recent >= 100 episodes
-            pw.reset(); order.reset()
-            episodes = 0
-            steps = 0
             promoted = False
             promoted_at = None
             info: Dict[str, Any] = {}
-            chunk_i = 0
             while episodes < self._max_num_episodes:
                 eps = max(self.exploration_rate(int(episodes / self._eps_episode_scale), k), self._eps_floor)  # scale 1, floor 0: the reference schedule
                 runner.train_steps(self._chunk_steps, eps)
                 steps += self._chunk_steps
                 s = eng.stats()
-                new_eps, new_ok, new_dec, new_rew = self._chunk_counters(s, s_prev)
-                new_eps, new_ok = int(new_eps), int(new_ok)
+                cc = self._chunk_counters(s, s_prev)
+                new_eps, new_ok, new_dec, new_rew = int(cc[0]), int(cc[1]), cc[2], cc[3]
                 s_prev = s
                 hit = None
                 if ordered:
@@ -281,14 +379,21 @@ class Trainer:
                 w_ok = sum(o for _, o in window)
                 # the reference divides by the deque length limit (100) also while the deque is filling (:222-224)
                 rate = w_ok / max(w_eps, self._successive_successful_episodes)
+                cnt_now = np.asarray(eng.get_tables()[2], dtype=np.float64)
+                self._alpha = self._mean_alpha(cnt_prev, cnt_now)
+                cnt_prev = cnt_now.copy()
                 info = {"Curent episode": episodes, "Remaining episodes": self._max_num_episodes - episodes + 1, "Exploration rate": eps,
-                        "Learning rate": self._alpha, "Success rate": rate, "Mean reward": new_rew / max(1, new_dec), "Agent periods": steps,
-                        "Curriculum step": k}
+                        "Learning rate": self._alpha, "Success rate": rate, "Mean reward": new_rew / max(1, new_dec),
+                        "Cumulative reward": new_rew / max(1, new_eps), "Agent periods": steps, "Curriculum step": k,
+                        "Termination condition": {c: int(v) for c, v in zip(_TERMINAL, cc[4:])}}
                 chunk_i += 1
-                if chunk_i % self._checkpoint_every == 0:
+                done_level = (hit is not None) if ordered else (rate > self._success_rate)
+                if chunk_i % self._checkpoint_every == 0 and not done_level:
+                    self._progress = {"level": k, "episodes": episodes, "steps": steps, "chunk_i": chunk_i, "window": [list(w) for w in window],
+                                      "pw": pw.get_state(), "order": order.get_state()}
                     self.save()
                 self.log(info)
-                if (hit is not None) if ordered else (rate > self._success_rate):
+                if done_level:
                     self._successes = deque([], maxlen=self._successive_successful_episodes)
                     promoted = True
                     if hit is not None:  # which judged episode (generation order) filled the reference's deque to > success_rate
@@ -303,8 +408,13 @@ class Trainer:
             if self._mode == "reference":
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))
-            self.save()
-            if not promoted and not exhausted:  # max_steps_per_level (build-specific bound) hit: stop here
+            self._progress = None  # between levels: a resumed run starts the next level from its beginning
+            if promoted or exhausted:
+                self._working_curriculum_step = min(k + 1, self._curriculum_steps)  # what a checkpoint taken now resumes at
+                self.save()
+                self._working_curriculum_step = k
+            else:  # max_steps_per_level (build-specific bound) hit: stop here
+                self.save()
                 break
         return self.history
 
@@ -316,11 +426,13 @@ class Trainer:
         path.mkdir(parents=True, exist_ok=True)
         f = path / "scalars.csv"
         new = not f.exists()
+        term = info.get("Termination condition") or {}
         with open(f, "a", newline="") as fh:
             w = csv.writer(fh)
             if new:
-                w.writerow(["Curriculum step", "Curent episode", "Agent periods", "Success Rate", "Exploration Rate", "Learning Rate", "Mean reward"])
-            w.writerow([info.get("Curriculum step"), info.get("Curent episode"), info.get("Agent periods"), info.get("Success rate"),
-                        info.get("Exploration rate"), info.get("Learning rate"), info.get("Mean reward")])
+                w.writerow(LOG_COLUMNS)
+            w.writerow([info.get("Curriculum step"), self._curriculum_episode_count, info.get("Curent episode"), info.get("Agent periods"),
+                        info.get("Success rate"), info.get("Cumulative reward"), info.get("Exploration rate"), info.get("Learning rate"),
+                        info.get("Mean reward")] + [term.get(c, 0) for c in _TERMINAL])
         if not self._quiet:
             print(" | ".join(f"{k}: {v}" for k, v in info.items()), flush=True)

@@ -22,14 +22,15 @@
 extern "C" {
 #endif
 
-#define DQL_ABI_VERSION 1
+#define DQL_ABI_VERSION 2
 
 typedef enum dql_status {
   DQL_OK = 0,
   DQL_EINVAL = -1, /* bad argument / unsupported configuration (Python: ValueError) */
   DQL_EHIP = -2,   /* HIP runtime error (Python: RuntimeError) */
   DQL_ESTATE = -3, /* call order violation, e.g. step before reset (Python: ValueError) */
-  DQL_ENOMEM = -4
+  DQL_ENOMEM = -4,
+  DQL_ERCCL = -5   /* RCCL error, or librccl could not be loaded (Python: RuntimeError) */
 } dql_status;
 
 /* CheckResult codes, declaration order of pkg/mdp.py:68-77 */
@@ -155,6 +156,9 @@ int dql_set_curriculum(dql_ctx* ctx, int32_t working_curriculum_step);
 int dql_reset(dql_ctx* ctx, const uint8_t* mask_or_null);
 /* one agent step with caller-supplied actions (uint8 per env, 0/1/2; two_axis: 2 per env); no table update */
 int dql_step(dql_ctx* ctx, const uint8_t* actions);
+/* same with the actions already in device memory (n_envs bytes, readable on the context's device): no copy, no host-side
+ * validation, fully asynchronous (the buffer must stay valid until the step has run); values other than 0 / 1 act as "hold" */
+int dql_step_dev(dql_ctx* ctx, const uint8_t* dev_actions);
 /* n fused agent steps: on-device eps-greedy guess + step + TD-target accumulation + table apply
  * (pkg/trainer.py:191-212 loop body for all envs at once) */
 int dql_train_steps(dql_ctx* ctx, int32_t n_steps, double eps);
@@ -196,9 +200,42 @@ int dql_stream_handle(dql_ctx* ctx, void** hip_stream);
  * dql_flush folds what is still pending (master tables and window) now.  Table getters / setters flush by themselves;
  * call it before all-reducing the window buffer directly. */
 int dql_flush(dql_ctx* ctx);
-int dql_apply_accum(dql_ctx* ctx); /* fold the (all-reduced) window into the base tables; master and acting tables restart from them */
+/* fold the (all-reduced) window into the base tables; master and acting tables restart from them.  With fold_per_step a
+ * cell visited m times (all ranks together) in a window of L launches takes min(m, L) learning-rate steps towards the
+ * window's mean target (L = 1: the single-launch rule), so the step size per env-step does not depend on the sync period */
+int dql_apply_accum(dql_ctx* ctx);
 int dql_get_accum(dql_ctx* ctx, int64_t* out); /* host copy of the 4*2835 window words, for tests */
 int dql_set_accum(dql_ctx* ctx, const int64_t* in);
+/* agent periods launched so far: the physics tick schedule and the per-period RNG counters are functions of it, so a
+ * checkpointed run resumes by restoring the env fields (dql_set_sim_state / _ints), the tables and this index */
+int dql_get_step_index(dql_ctx* ctx, int64_t* step_index);
+int dql_set_step_index(dql_ctx* ctx, int64_t step_index);
+/* checkpoint barrier: fold what is pending and make the acting tables equal to the master tables (what a resumed run starts from) */
+int dql_publish_tables(dql_ctx* ctx);
+
+/* ---- RCCL communicator (ncclAllReduce(ncclInt64, ncclSum) of the window over xGMI; no PyTorch) ----
+ * librccl.so is loaded on first use (dlopen), so single-GPU users never pay for it.  One process per GPU: rank 0 calls
+ * dql_comm_unique_id and hands the 128 bytes to the other ranks out of band (the Python host uses a file, comm.py), then
+ * every rank calls dql_comm_create.  The host-buffer collectives below are the Trainer's control plane (chunk counters,
+ * judged envs' episode logs, the bench's max-over-ranks timing); they stage through a device buffer on the communicator's
+ * own stream and return when the result is in `inout` / `out`. */
+#define DQL_COMM_ID_BYTES 128
+typedef struct dql_comm dql_comm;
+enum { DQL_OP_SUM = 0, DQL_OP_MAX = 1 };
+int dql_comm_unique_id(uint8_t* id_out /* [DQL_COMM_ID_BYTES] */);
+int dql_comm_create(int device, int32_t rank, int32_t world, const uint8_t* id /* [DQL_COMM_ID_BYTES] */, dql_comm** out);
+int dql_comm_destroy(dql_comm* comm);
+int dql_comm_info(dql_comm* comm, int32_t* rank, int32_t* world, int32_t* device);
+int dql_comm_allreduce_f64(dql_comm* comm, double* inout, int64_t n, int32_t op);
+int dql_comm_allreduce_i64(dql_comm* comm, int64_t* inout, int64_t n, int32_t op);
+int dql_comm_allgather_u64(dql_comm* comm, const uint64_t* in, int64_t n, uint64_t* out /* [world][n], rank order */);
+int dql_comm_barrier(dql_comm* comm);
+/* data path: the context's window is summed over the ranks in place, on the context's stream (asynchronous; the fold
+ * that follows, dql_apply_accum, is stream-ordered behind it).  Flushes first.  NULL detaches. */
+int dql_attach_comm(dql_ctx* ctx, dql_comm* comm_or_null);
+int dql_allreduce_window(dql_ctx* ctx);
+/* average device time of the exchanges (all-reduce + fold) made while the kernel timer was armed (dql_kernel_timer) */
+int dql_sync_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* syncs);
 
 /* ---- stats / timing ---- */
 int dql_stats_get(dql_ctx* ctx, dql_stats* out);
@@ -239,9 +276,15 @@ int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t st
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:
- * sa int32[n] = cell index (idx*3+action), ns int32[n] = packed next state; tables updated in place */
+ * sa int32[n] = cell index (idx*3+action), ns int32[n] = packed next state; tables updated in place.
+ * quirks: DQL_Q_UPDATE_TABLE_A_ONLY (B1/B2) = the reference: always Q_table_a, valued by itself; cleared = Double Q-learning:
+ * coin[i] (required then: 0 -> Q_table_a, 1 -> Q_table_b; the caller draws it where the reference draws its unused uniform)
+ * picks the table to update and the OTHER table values the picked table's greedy action at s'.
+ * DQL_Q_BOOTSTRAP_ON_POS_CHANGE (B3) = bootstrap only when the position bin changed; cleared = bootstrap unless done[i]
+ * (required then).  Other quirk bits do not concern the agent and are ignored. */
 int dql_agent_update(int device, double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns,
-                     const double* alpha, double gamma, const double* reward, int64_t n, uint32_t quirks);
+                     const double* alpha, double gamma, const double* reward, int64_t n, uint32_t quirks,
+                     const uint8_t* coin_or_null, const uint8_t* done_or_null);
 
 /* DoubleQLearningAgent.transfer_learning (pkg/double_q_learning.py:77-89) on host tables: Q[k] = Q[k-1] * ratio (k = 0 wraps, B6) */
 int dql_agent_transfer(int device, double* qa, double* qb, int32_t k, double ratio);

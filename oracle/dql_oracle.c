@@ -949,17 +949,24 @@ EXPORT void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 EXPORT void orc_agent_predict(const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
 }
-/* DoubleQLearningAgent.update replayed in order (pkg/double_q_learning.py:91-146; B1: always table a) */
+/* DoubleQLearningAgent.update replayed in order (pkg/double_q_learning.py:91-146).  Reference quirks: B1/B2 (always table a,
+ * valued by itself, DQL_Q_UPDATE_TABLE_A_ONLY) and B3 (bootstrap only when the position bin changed,
+ * DQL_Q_BOOTSTRAP_ON_POS_CHANGE).  With B1/B2 cleared: Double Q-learning, coin[i] picks the table to update (the draw the
+ * reference makes and ignores, :101), the other table values the picked table's greedy action; with B3 cleared the mask is
+ * !done[i]. */
 EXPORT void orc_agent_update(double* qa, double* qb, double* count, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma,
-                             const double* reward, int64_t n, uint32_t quirks) {
-  (void)qb; (void)quirks;
+                             const double* reward, int64_t n, uint32_t quirks, const uint8_t* coin, const uint8_t* done) {
+  const int dbl = !(quirks & DQL_Q_UPDATE_TABLE_A_ONLY);
   for (int64_t i = 0; i < n; ++i) {
     count[sa[i]] += 1;
-    const double* qn = qa + ns[i] * 3;
-    const double best = qn[argmax3(qn[0], qn[1], qn[2])];
-    const int mask = ((sa[i] / 3) / 63) % 3 != (ns[i] / 63) % 3;
-    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qa[sa[i]]);
-    qa[sa[i]] += loss;
+    const int sel_b = dbl && coin[i] != 0;
+    double* qsel = sel_b ? qb : qa;
+    const double* qval = dbl ? (sel_b ? qa : qb) : qa;
+    const double* qn = qsel + ns[i] * 3;
+    const double best = qval[ns[i] * 3 + argmax3(qn[0], qn[1], qn[2])];
+    const int mask = (quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) ? (((sa[i] / 3) / 63) % 3 != (ns[i] / 63) % 3) : !done[i];
+    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qsel[sa[i]]);
+    qsel[sa[i]] += loss;
   }
 }
 /* transfer_learning (pkg/double_q_learning.py:77-89), k = 0 wraps to the last level (B6) */
@@ -976,7 +983,10 @@ EXPORT void orc_transfer(double* qa, double* qb, int k, double ratio, int n_leve
  * accum = [4][N_CELLS]: Q_table_a's {sums, visits}, then Q_table_b's; one shared visit counter (state_action_counter,
  * pkg/double_q_learning.py:100): table a's visits of a launch take the learning rates alpha(c) .. alpha(c + m_a - 1),
  * table b's the next m_b. */
-EXPORT void orc_apply_accum(double* qa, double* qb, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min, int per_step) {
+/* per_step: one learning-rate step per launch the accumulators cover (n_launch = 1 for a launch's own fold, the window
+ * length for the multi-rank window), never more steps than visits */
+EXPORT void orc_apply_accum(double* qa, double* qb, double* count, int64_t* accum, const double* alpha_tab, int32_t n_tab, double alpha_min, int per_step,
+                            int64_t n_launch) {
   for (int cell = 0; cell < DQL_N_CELLS; ++cell) {
     for (int t = 0; t < 2; ++t) {
       int64_t* acc = accum + t * 2 * DQL_N_CELLS;
@@ -986,7 +996,7 @@ EXPORT void orc_apply_accum(double* qa, double* qb, double* count, int64_t* accu
       const double tbar = ((double)acc[cell] * (1.0 / (double)(1ll << DQL_TARGET_FRAC_BITS))) / (double)m;
       const int64_t c0 = (int64_t)count[cell];
       double shrink = 1.0; int64_t j = 0;
-      const int64_t m_eff = per_step ? 1 : m;
+      const int64_t m_eff = per_step ? (m < n_launch ? m : n_launch) : m;
       for (; j < m_eff && c0 + j < n_tab; ++j) shrink *= (1.0 - alpha_tab[c0 + j]);
       int64_t rem = m_eff - j;
       if (rem > 0) { double base = 1.0 - alpha_min, pw = 1.0; while (rem) { if (rem & 1) pw *= base; base *= base; rem >>= 1; } shrink *= pw; }

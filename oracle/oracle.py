@@ -146,9 +146,9 @@ class Oracle:
         self.set_fields(reals, ints)
 
     # ---- stepping ----
-    def _contract(self, qa, qb, count, accum):
+    def _contract(self, qa, qb, count, accum, n_launch=1):
         lib().orc_apply_accum(_p(qa), _p(qb), _p(count), _p(accum), _p(self.alpha_tab), C.c_int32(len(self.alpha_tab)),
-                              C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step))
+                              C.c_double(self.cfg.alpha_min), C.c_int(self.cfg.fold_per_step), C.c_int64(max(1, int(n_launch))))
 
     def _fold_pending(self):
         if self.pending is not None:
@@ -160,6 +160,11 @@ class Oracle:
     def flush(self):
         """Fold the last launch's accumulators into the master tables now (the acting tables do not change)."""
         self._fold_pending()
+
+    def publish_tables(self):
+        """checkpoint barrier (dql_publish_tables): everything folded, acting tables = master tables"""
+        self.flush()
+        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
 
     def _period(self, mode, eps=0.0, actions=None):
         j = self.step_index
@@ -186,6 +191,8 @@ class Oracle:
         self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
         if mode == 0:
             self.pending = self.accum.copy()
+            if self.windowed:
+                self.window_launches += 1
         self.accum[:] = 0
 
     # ---- windowed (multi-rank) semantics: same interface as the product Engine ----
@@ -194,6 +201,7 @@ class Oracle:
         if on and not self.windowed:
             self.qa_base = self._qa.copy(); self.qb_base = self._qb.copy(); self.count_base = self._count.copy()
             self.window = np.zeros(4 * N_CELLS, dtype=np.int64)
+            self.window_launches = 0
         self.windowed = bool(on)
 
     def get_accum(self):
@@ -206,7 +214,8 @@ class Oracle:
     def apply_accum(self):
         """fold the (all-reduced) window into the base tables; master and acting tables restart from the base"""
         assert self.pending is None, "flush before reducing the window"
-        self._contract(self.qa_base, self.qb_base, self.count_base, self.window)
+        self._contract(self.qa_base, self.qb_base, self.count_base, self.window, self.window_launches)
+        self.window_launches = 0
         self._qa[:] = self.qa_base; self._qb[:] = self.qb_base; self._count[:] = self.count_base
         self.qa_act[:] = self.qa_base; self.qb_act[:] = self.qb_base
 
@@ -272,11 +281,13 @@ def agent_predict(qa, qb, idx):
     return out
 
 
-def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks=0x3F):
+def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks=0x3F, coin=None, done=None):
     sa = np.ascontiguousarray(sa, dtype=np.int32); ns = np.ascontiguousarray(ns, dtype=np.int32)
     alpha = _f64(alpha); reward = _f64(reward)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    coin, done = u8(coin), u8(done)
     lib().orc_agent_update(_p(qa), _p(qb), _p(count), _p(sa), _p(ns), _p(alpha), C.c_double(gamma), _p(reward), C.c_int64(len(sa)),
-                           C.c_uint32(quirks))
+                           C.c_uint32(quirks), _p(coin) if coin is not None else None, _p(done) if done is not None else None)
 
 
 def transfer(qa, qb, k, ratio):

@@ -5,6 +5,8 @@ curriculum training of the tabular Double-Q landing agent on one MI355X.
     python scripts/training.py [--envs 4096] [--mode reference|paper] [--out DIR] [--max-steps-per-level N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         scripts/training.py --envs 262144 --sync-period 4        # BASELINE config 4: one rank per GPU, RCCL table exchange
+(torch.distributed.run is only the process launcher here; any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+MASTER_PORT will do.  The ranks themselves never import PyTorch.)
 """
 import argparse
 import json
@@ -27,8 +29,7 @@ if __name__ == "__main__":
     ap.add_argument("--eps-floor", type=float, default=0.0)
     ap.add_argument("--success-rate", type=float, default=0.96, help="promotion threshold (reference: 0.96, pkg/trainer.py:25)")
     ap.add_argument("--promotion-rule", default="ordered", choices=["ordered", "aggregate"])
-    ap.add_argument("--sync-period", type=int, default=1, help="agent periods between table exchanges (multi-GPU)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--sync-period", type=int, default=None, help="agent periods between table exchanges (default: none on one GPU, 2 on several; given on one GPU it runs the same windowed schedule)")
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--t-max", type=int, default=20)
     ap.add_argument("--judge-envs", type=int, default=4096)
@@ -36,23 +37,17 @@ if __name__ == "__main__":
     a = ap.parse_args()
     import os
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:  # torch first: it brings its own HIP runtime, which has to be the one the process uses
-        import torch
-        import torch.distributed as dist
-        local %= max(1, torch.cuda.device_count())  # rehearsals with more ranks than GPUs (gloo backend) share the devices
-        torch.cuda.set_device(local)
-        dist.init_process_group(a.backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", local)} if a.backend == "nccl" else {}))
     import __graft_entry__ as g
     g.build_hip()
     from dql_multirotor_landing_amd.config import F32, F64
     from dql_multirotor_landing_amd.trainer import Trainer
+    # one rank per GPU: the Trainer picks RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* up by itself (comm.RcclComm.from_env, RCCL inside libdql_hip.so)
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local,
                  promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
                  successive_successful_episodes=a.window,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes if a.max_episodes is not None else max(50000, 64 * a.envs), quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
     hist = tr.curriculum_training()
     if rank == 0:
         print(json.dumps({"history": hist, "save_path": str(tr._save_path), "world": world}, indent=1))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if tr._comm is not None:
+        tr._comm.barrier()

@@ -1,0 +1,69 @@
+"""CPU-side checks of the multi-rank plumbing that needs no GPU: how ranks find rank 0's unique id, and that
+`bench.py --gpus N` never degrades to a silent single-GPU measurement."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+_PRINT_PATH = "import sys; sys.path.insert(0, %r); from dql_multirotor_landing_amd.comm import id_file_path; print(id_file_path(0)); print(id_file_path(1))" % str(ROOT)
+
+
+def _child_paths(port, extra=None):
+    env = dict(os.environ, MASTER_PORT=str(port))
+    env.pop("DQL_COMM_ID_FILE", None)
+    env.update(extra or {})
+    return subprocess.run([sys.executable, "-c", _PRINT_PATH], env=env, capture_output=True, text=True, check=True).stdout.split("\n")[:2]
+
+
+def test_sibling_ranks_agree_on_the_id_file():
+    """Ranks are siblings (children of the launcher): same parent => same file name, without any communication; another job
+    (other port, or another parent) gets another name, so a stale file is never picked up."""
+    a, b = _child_paths(29500), _child_paths(29500)
+    assert a == b and a[0] != a[1]
+    assert _child_paths(29501)[0] != a[0]
+    assert str(os.getpid()) in a[0]  # keyed by the parent (this process) ...
+    via_shell = subprocess.run(["bash", "-c", f"exec 3>&1; ( {sys.executable} -c {_PRINT_PATH!r} ) "], env=dict(os.environ, MASTER_PORT="29500"),
+                               capture_output=True, text=True, check=True).stdout.split("\n")[0]
+    assert via_shell != a[0]  # ... and another parent gives another name
+    assert _child_paths(29500, {"DQL_COMM_ID_FILE": "/tmp/x.id"}) == ["/tmp/x.id", "/tmp/x.id.1"]
+
+
+def test_comm_entry_points_fail_loudly_without_gpu():
+    from dql_multirotor_landing_amd import _lib
+    lib = _lib.load()
+    n = C.c_int(0)
+    if lib.dql_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert lib.dql_comm_create(0, 0, 1, uid, C.byref(h)) == _lib.EHIP and not h.value
+    assert lib.dql_comm_create(0, 2, 2, uid, C.byref(h)) == _lib.EINVAL  # rank out of range
+    assert lib.dql_comm_barrier(None) == _lib.EINVAL
+    assert lib.dql_comm_destroy(None) == 0
+    from dql_multirotor_landing_amd.comm import RcclComm
+    with pytest.raises(RuntimeError):
+        RcclComm(0, 1, 0)
+    assert RcclComm.from_env() is None or os.environ.get("WORLD_SIZE", "1") != "1"
+
+
+def test_bench_gpus_2_without_two_gpus_fails_loudly():
+    """The driver starts `python bench.py --gpus N` without a launcher: it must start N ranks or fail, never print n_gpus: 1."""
+    from dql_multirotor_landing_amd import _lib
+    n = C.c_int(0)
+    if _lib.load().dql_device_count(C.byref(n)) == 0 and n.value >= 2:
+        pytest.skip("two GPUs are visible here")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-curriculum",
+                        "--large-envs", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
+    assert "fewer than 2 ranks ran" in r.stderr and "GPU" in r.stderr
+    # a launcher that started a different number of ranks than --gpus says is an error too
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "3", "--no-cpu-baseline", "--no-curriculum"], cwd=ROOT,
+                       env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "launcher started 2" in r.stderr

@@ -1,7 +1,7 @@
 """world_size-2 coverage of the multi-GPU path on CPU (gloo): env sharding by global env id, the int64 window
 all-reduce and the base/work table semantics of dql_multirotor_landing_amd.dist.ShardedRunner.  The compute engine
-injected here is the CPU oracle (allowed in tests only); on the GPU the same runner drives the HIP Engine with the
-RCCL reducer."""
+injected here is the CPU oracle and the communicator a torch/gloo stand-in (tests/_torch_comm.py; both allowed in tests
+only); on the GPU the same runner drives the HIP Engine with the RCCL reducer of libdql_hip.so."""
 import os
 import socket
 import sys
@@ -20,13 +20,13 @@ def _free_port():
 
 
 def _worker(rank, world, port, sync_period, out_dir):
-    sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch.distributed as dist
+    from _torch_comm import HostWindowReducer
     from dql_multirotor_landing_amd.config import DqlConfig, F64
-    from dql_multirotor_landing_amd.dist import HostWindowReducer, ShardedRunner, shard_range
+    from dql_multirotor_landing_amd.dist import ShardedRunner, shard_range
     from oracle.oracle import Oracle
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lo, hi = shard_range(N_TOTAL, rank, world)
     eng = Oracle(DqlConfig(dtype=F64), hi - lo, seed=42, env_id_offset=lo)
     run = ShardedRunner(eng, HostWindowReducer(eng), sync_period=sync_period)
@@ -119,8 +119,13 @@ def _oracle_engine_class():
     class OracleEngine:  # the Engine surface the Trainer uses, computed by the CPU oracle (tests only)
         def __init__(self, cfg, n, seed=42, device=0, env_id_offset=0):
             self.o = Oracle(cfg, n, seed=seed, env_id_offset=env_id_offset)
+            self.n = n
         def __getattr__(self, name):
             return getattr(self.o, name)
+        def step_index(self):
+            return self.o.step_index
+        def set_step_index(self, j):
+            self.o.publish_tables(); self.o.step_index = int(j)
         def get_tables(self):
             return self.o.qa.copy(), self.o.qb.copy(), self.o.count.copy()
         def stats(self):
@@ -135,14 +140,14 @@ def _strip(hist):
 
 
 def _trainer_worker(rank, world, port, out_dir):
-    sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import json
     import torch.distributed as dist
+    from _torch_comm import TorchComm
     import dql_multirotor_landing_amd.trainer as T
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     T.Engine = _oracle_engine_class()
-    tr = T.Trainer(save_path=Path(out_dir) / "run", **TR_KW)  # picks the process group up by itself
+    tr = T.Trainer(save_path=Path(out_dir) / "run", comm=TorchComm(), **TR_KW)
     assert tr._world == 2 and tr._rank == rank
     hist = tr.curriculum_training()
     qa, qb, cnt = tr._engine.get_tables()
@@ -165,11 +170,8 @@ def test_trainer_curriculum_two_ranks_equals_single_process(tmp_path, monkeypatc
     assert (tmp_path / "run" / "Q_table_a.npy").exists()  # rank 0 wrote the checkpoint
     monkeypatch.setattr(T, "Engine", _oracle_engine_class())
 
-    class LocalReducer:  # world size 1 on the same exchange schedule
-        def __init__(self, eng): self.eng = eng
-        def all_reduce(self): self.eng.flush()
-
-    single = T.Trainer(save_path=tmp_path / "single", reducer_factory=LocalReducer, **TR_KW)
+    # world size 1 with the same sync_period: the Trainer puts itself on the windowed schedule (dist.LocalWindowReducer)
+    single = T.Trainer(save_path=tmp_path / "single", **TR_KW)
     hs = json.loads(json.dumps(_strip(single.curriculum_training())))
     assert hs == h0
     assert any(h["promoted"] for h in hs) and sum(h["episodes"] for h in hs) > 0
@@ -178,3 +180,42 @@ def test_trainer_curriculum_two_ranks_equals_single_process(tmp_path, monkeypatc
         z = np.load(tmp_path / f"trainer_rank{r}.npz")
         np.testing.assert_array_equal(z["qa"], qa)
         np.testing.assert_array_equal(z["count"], cnt)
+
+
+def test_trainer_resume_equals_uninterrupted_run(tmp_path, monkeypatch):
+    """Stop after a mid-level checkpoint, Trainer.load, finish: history and tables equal the uninterrupted run (oracle engine).
+    The checkpoint carries every env's simulator state, the period index (RNG counters, tick schedule), the level's episode
+    count (exploration schedule) and the promotion bookkeeping; the level's transfer is not applied a second time."""
+    import json
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    kw = dict(curriculum_steps=3, n_envs=64, chunk_steps=8, checkpoint_every=3, max_num_episodes=120, t_max=3,
+              successive_successful_episodes=10, success_rate=0.25, mode="paper", judge_envs=48, eps_floor=0.3)
+    for sync in (None, 2):
+        full = T.Trainer(save_path=tmp_path / f"full{sync}" / "01-01-2026 10:00:00", sync_period=sync, **kw)
+        h_full = _strip(full.curriculum_training())
+        assert len(h_full) == 3 and sum(h["agent_periods"] for h in h_full) > 3 * 8 * 3  # several checkpoints were taken
+
+        class Stop(Exception):
+            pass
+
+        part = T.Trainer(save_path=tmp_path / f"part{sync}" / "01-01-2026 10:00:00", sync_period=sync, **kw)
+        n_saves = {"n": 0}
+        real_save = part.save
+        def save_then_stop():
+            real_save()
+            if part._progress is not None and part._progress["level"] == 1:
+                n_saves["n"] += 1
+                if n_saves["n"] == 1:
+                    raise Stop()  # "power cut" right after the first mid-level checkpoint of level 1
+        part.save = save_then_stop
+        with pytest.raises(Stop):
+            part.curriculum_training()
+        st = json.loads((tmp_path / f"part{sync}" / "01-01-2026 10:00:00" / "trainer.json").read_text())
+        assert st["progress"]["level"] == 1 and st["build"]["eps_floor"] == 0.3 and st["build"]["judge_envs"] == 48 and st["build"]["sync_period"] == sync
+        back = T.Trainer.load(tmp_path / f"part{sync}")
+        assert back._working_curriculum_step == 1 and back._eps_floor == 0.3 and back._chunk_steps == 8
+        h_back = _strip(back.curriculum_training())
+        assert json.loads(json.dumps(h_back)) == json.loads(json.dumps(h_full))
+        for a, b in zip(back._engine.get_tables(), full._engine.get_tables()):
+            np.testing.assert_array_equal(a, b)

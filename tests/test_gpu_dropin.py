@@ -207,8 +207,9 @@ def test_trainer_full_curriculum_hip_equals_oracle_engine(tmp_path, monkeypatch)
 
 
 def test_sharded_trainer_two_ranks_on_one_gpu_equals_single_process(tmp_path):
-    """scripts/training.py under torch.distributed.run with 2 ranks (gloo exchange, both ranks on GPU 0 — the RCCL path needs
-    one GPU per rank and is exercised by the driver's multi-GPU runs): sharded HIP engines + all-reduced counters + gathered
+    """The sharded Trainer under torch.distributed.run with 2 ranks (tests/_rehearsal_training.py: gloo stand-in communicator, both
+    ranks on GPU 0 — the RCCL path needs one GPU per rank and is exercised by the driver's multi-GPU runs and, on one rank, by
+    test_gpu_parity.py::test_rccl_reducer_world_size_1): sharded HIP engines + all-reduced counters + gathered
     episode logs give the history and tables of one process running all envs on the same exchange schedule.  Exact for
     sync_period <= 2: launch j acts on tables folded up to launch j-2, so with an exchange every second period no rank ever
     acts on updates the others have not seen; longer windows trade that for fewer exchanges (bounded staleness)."""
@@ -221,20 +222,15 @@ def test_sharded_trainer_two_ranks_on_one_gpu_equals_single_process(tmp_path):
             "--window", "20", "--success-rate", "0.2", "--judge-envs", "400"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(root / "scripts" / "training.py"), "--backend", "gloo", "--out", str(tmp_path / "two"), *args],
+                        "--master-port", str(port), str(root / "tests" / "_rehearsal_training.py"), "--out", str(tmp_path / "two"), *args],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout[r.stdout.index("{"):])
     assert out["world"] == 2
     strip = lambda hist: [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
 
-    class LocalReducer:
-        def __init__(self, eng): self.eng = eng
-        def all_reduce(self): self.eng.flush()
-
     one = T.Trainer(n_envs=600, mode="paper", chunk_steps=16, sync_period=2, max_num_episodes=700, curriculum_steps=3, t_max=4,
-                    successive_successful_episodes=20, success_rate=0.2, judge_envs=400, save_path=tmp_path / "one", checkpoint_every=50,
-                    reducer_factory=LocalReducer)
+                    successive_successful_episodes=20, success_rate=0.2, judge_envs=400, save_path=tmp_path / "one", checkpoint_every=50)
     h1 = json.loads(json.dumps(strip(one.curriculum_training())))
     assert strip(out["history"]) == h1 and [h["level"] for h in h1] == [0, 1, 2]
     for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):

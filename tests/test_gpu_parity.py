@@ -164,65 +164,96 @@ def test_windowed_accumulation_matches_oracle(mods):
 
 _RCCL_SCRIPT = r"""
 import os, sys
-import torch  # torch first: its bundled HIP runtime must be the one the process binds (same SONAME as /opt/rocm's)
-import torch.distributed as dist
 import numpy as np
 sys.path.insert(0, os.getcwd())
+from dql_multirotor_landing_amd import _lib
+from dql_multirotor_landing_amd.comm import RcclComm
 from dql_multirotor_landing_amd.config import DqlConfig, F32
-from dql_multirotor_landing_amd.dist import ShardedRunner, TorchWindowReducer
+from dql_multirotor_landing_amd.dist import LocalWindowReducer, RcclWindowReducer, ShardedRunner
 from dql_multirotor_landing_amd.engine import Engine
 from oracle.oracle import Oracle
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1)
+comm = RcclComm(rank=0, world=1, device=0)   # ncclGetUniqueId + ncclCommInitRank inside libdql_hip.so
+assert "torch" not in sys.modules, "the RCCL path must not need PyTorch"
 n = 512
 eng = Engine(DqlConfig(dtype=F32), n, seed=33)
 orc = Oracle(DqlConfig(dtype=F32), n, seed=33); orc.set_windowed(True)
-run = ShardedRunner(eng, TorchWindowReducer(eng, 0), sync_period=4)
+run = ShardedRunner(eng, RcclWindowReducer(eng, comm), sync_period=4)
 run.train_steps(12, 0.7)
 for _ in range(3):
     orc.train_steps(4, 0.7); orc.flush(); orc.apply_accum()
-eng.sync(); torch.cuda.synchronize()
+eng.sync()
 qa, qb, cnt = eng.get_tables()
 er, ei = eng.get_fields(); o_r, o_i = orc.get_fields()
 assert np.array_equal(qa.ravel(), orc.qa) and np.array_equal(cnt.ravel(), orc.count) and cnt.sum() > 0
 assert np.array_equal(ei, o_i) and np.array_equal(er, o_r)
-# the Trainer's control plane over the same backend: counters summed and episode logs gathered as GPU tensors, table
-# exchange through TorchWindowReducer; one rank, so the run must equal the local-exchange run
+# exchange timing hooks
+eng.kernel_timer(True); run.train_steps(8, 0.7); ms, k = eng.sync_time_ms(); eng.kernel_timer(False)
+assert k == 2 and 0 < ms < 50, (ms, k)
+# control plane through RCCL: sums, max, gathers on host arrays
+v = comm.all_reduce_sum(np.array([1.5, -2.0, 3e9])); assert np.array_equal(v, [1.5, -2.0, 3e9])
+v = comm.all_reduce_max(np.array([7.25])); assert v[0] == 7.25
+v = comm.all_reduce_sum_i64(np.array([1 << 60, -5])); assert list(v) == [1 << 60, -5]
+d = np.arange(6, dtype=np.uint64).reshape(2, 3) + np.uint64(1 << 63); g = d[::-1].copy()
+gd, gg = comm.all_gather_masks(d, g); assert np.array_equal(gd, d) and np.array_equal(gg, g)
+gd, gg = comm.all_gather_masks(d[:0], g[:0]); assert gd.shape == (0, 3)
+comm.barrier()
+# error paths: wrong device, detached context
+try:
+    eng2 = Engine(DqlConfig(dtype=F32), 64, seed=1); eng2.set_windowed(True); eng2.allreduce_window()
+    raise SystemExit("allreduce without a communicator must fail")
+except ValueError:
+    pass
+# the Trainer's control plane over the same communicator: counters summed and episode logs gathered by RCCL, table
+# exchange through RcclWindowReducer; one rank, so the run must equal the local-exchange run (configs[3] flavour: the 2-level
+# curriculum at 32 768 envs per rank with sync_period 2)
 import json, tempfile
 import dql_multirotor_landing_amd.trainer as T
-from dql_multirotor_landing_amd.dist import TorchComm
-class LocalReducer:
-    def __init__(self, e): self.e = e
-    def all_reduce(self): self.e.flush()
-kw = dict(n_envs=700, mode="paper", chunk_steps=16, sync_period=4, max_num_episodes=600, curriculum_steps=2, t_max=4,
+kw = dict(n_envs=32768, mode="paper", chunk_steps=16, sync_period=2, max_num_episodes=40000, curriculum_steps=2, t_max=4,
           successive_successful_episodes=20, success_rate=0.2, judge_envs=300, checkpoint_every=10**9)
 strip = lambda hist: [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
 d = tempfile.mkdtemp()
-comm = TorchComm(None, 0)
-assert comm.backend == "nccl" and comm.world == 1
 a = T.Trainer(save_path=d + "/a", comm=comm, reducer_factory=comm.reducer, **kw)
 ha = strip(a.curriculum_training())
-b = T.Trainer(save_path=d + "/b", reducer_factory=LocalReducer, **kw)
+b = T.Trainer(save_path=d + "/b", reducer_factory=LocalWindowReducer, **kw)
 hb = strip(b.curriculum_training())
 assert ha == hb and len(ha) == 2, (ha, hb)
 for x, y in zip(a._engine.get_tables(), b._engine.get_tables()):
     assert np.array_equal(x, y)
-dist.destroy_process_group()
+assert "torch" not in sys.modules
+comm.close()
 print("RCCL_OK")
 """
 
 
 def test_rccl_reducer_world_size_1():
-    """The torch.distributed (RCCL) plumbing of the exchange on a single rank, in its own process (torch imported
-    before the HIP library): external window buffer owned by torch, all-reduce on the engine's stream, fold.  With one
-    rank the sum is the identity, so results equal the windowed oracle."""
+    """The RCCL exchange of libdql_hip.so on a single rank, in its own process and WITHOUT PyTorch: unique id, communicator,
+    ncclAllReduce(int64, sum) of the window on the engine's stream, fold; the host-buffer control-plane collectives; the
+    Trainer on the RCCL communicator.  With one rank the sum is the identity, so results equal the windowed oracle and
+    the local-exchange Trainer."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts N ranks itself; on a box with fewer GPUs it must fail loudly, never print n_gpus: 1."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from dql_multirotor_landing_amd import _lib
+    import ctypes as C
+    n = C.c_int(0)
+    _lib.check(_lib.load().dql_device_count(C.byref(n)))
+    want = n.value + 1
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(want), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-curriculum",
+                        "--large-envs", "0"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert '"n_gpus"' not in r.stdout and "GPU" in r.stderr, r.stderr[-3000:]
 
 
 def test_two_axis_bit_exact_f64_and_external_actions(mods):
