@@ -85,6 +85,7 @@ SYMBOLS = {
     "dql_timer_stop": (C.c_int, [_vp, C.POINTER(_dbl)]),
     "dql_kernel_timer": (C.c_int, [_vp, _i32]),
     "dql_kernel_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    "dql_delay": (C.c_int, [_vp, _dbl]),
     "dql_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "dql_episode_log_enable": (C.c_int, [_vp, _i32]),
     "dql_episode_log_read": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),

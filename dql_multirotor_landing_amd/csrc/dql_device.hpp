@@ -228,14 +228,14 @@ template <typename T> struct HotK {
 };
 DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   HotK<float> h;
-#define DQL_H(f) h.f = to_vgpr(s.f)
-  DQL_H(dt); DQL_H(g); DQL_H(inv_m); DQL_H(I[0]); DQL_H(I[1]); DQL_H(I[2]); DQL_H(inv_I[0]); DQL_H(inv_I[1]); DQL_H(inv_I[2]);
-  DQL_H(l); DQL_H(h); DQL_H(kf); DQL_H(lkf); DQL_H(kmkf); DQL_H(aup); DQL_H(adn); DQL_H(omax); DQL_H(cd); DQL_H(crd);
-  DQL_H(kR[0]); DQL_H(kR[1]); DQL_H(kR[2]); DQL_H(kW[0]); DQL_H(kW[1]); DQL_H(kW[2]); DQL_H(ia); DQL_H(ib); DQL_H(ic);
-  DQL_H(vz_kp); DQL_H(vz_ki); DQL_H(vz_lo); DQL_H(vz_hi); DQL_H(vz_wind); DQL_H(vz_sp);
-  DQL_H(yw_kp); DQL_H(yw_ki); DQL_H(yw_lo); DQL_H(yw_hi); DQL_H(yw_wind); DQL_H(yw_sp);
-  DQL_H(bw_k1); DQL_H(bw_inv); DQL_H(mp_top); DQL_H(mp_hx); DQL_H(mp_hy); DQL_H(bottom);
-#undef DQL_H
+#define DQL_HOT(f) h.f = to_vgpr(s.f)
+  DQL_HOT(dt); DQL_HOT(g); DQL_HOT(inv_m); DQL_HOT(I[0]); DQL_HOT(I[1]); DQL_HOT(I[2]); DQL_HOT(inv_I[0]); DQL_HOT(inv_I[1]); DQL_HOT(inv_I[2]);
+  DQL_HOT(l); DQL_HOT(h); DQL_HOT(kf); DQL_HOT(lkf); DQL_HOT(kmkf); DQL_HOT(aup); DQL_HOT(adn); DQL_HOT(omax); DQL_HOT(cd); DQL_HOT(crd);
+  DQL_HOT(kR[0]); DQL_HOT(kR[1]); DQL_HOT(kR[2]); DQL_HOT(kW[0]); DQL_HOT(kW[1]); DQL_HOT(kW[2]); DQL_HOT(ia); DQL_HOT(ib); DQL_HOT(ic);
+  DQL_HOT(vz_kp); DQL_HOT(vz_ki); DQL_HOT(vz_lo); DQL_HOT(vz_hi); DQL_HOT(vz_wind); DQL_HOT(vz_sp);
+  DQL_HOT(yw_kp); DQL_HOT(yw_ki); DQL_HOT(yw_lo); DQL_HOT(yw_hi); DQL_HOT(yw_wind); DQL_HOT(yw_sp);
+  DQL_HOT(bw_k1); DQL_HOT(bw_inv); DQL_HOT(mp_top); DQL_HOT(mp_hx); DQL_HOT(mp_hy); DQL_HOT(bottom);
+#undef DQL_HOT
   h.bw_k2 = s.bw_k2;  // only steers a wave-uniform branch
   return h;
 }

@@ -311,6 +311,12 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
   }
 #ifdef DQL_WAVE_CLOCK
   if (DQL_WAVE_CLOCK == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); clk1 = wall_clock64(); }
+  if (DQL_WAVE_CLOCK == 8) {  // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and the XCC id above it (tools/exp_placement.py)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    clk1 = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
   if (a.elog && (tid & 63) == 0) { const long long w = i >> 6, nw = (a.n + 63) >> 6; if (w < nw) { a.elog[w] = clk0; a.elog[nw + w] = clk1; } }
 #endif
 }
@@ -349,6 +355,11 @@ __global__ void k_mark_reset(int4* si, const uint8_t* mask, long long n) {
   int4 v = si[i];
   v.w |= (FL_DONE << 8);
   si[i] = v;
+}
+// holds a stream for `ticks` of the 100 MHz wall clock (cohort phase offset, dql_delay): one wave, exits on time or on the iteration bound
+__global__ void k_delay(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
 }
 __global__ void k_transfer(double* qa, double* qb, int k, int src, double ratio) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1081,6 +1092,14 @@ int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
   for (size_t i = 0; i + 1 < x->kev.size(); i += 2) { float f = 0; HIP_TRY(hipEventElapsedTime(&f, x->kev[i], x->kev[i + 1])); tot += f; ++n; }
   if (avg_ms) *avg_ms = n ? tot / (double)n : 0.0;
   if (launches) *launches = n;
+  return DQL_OK;
+}
+int dql_delay(dql_ctx* x, double microseconds) {
+  CHECK_CTX(x);
+  if (!(microseconds >= 0.0) || microseconds > 1e5) return fail(DQL_EINVAL, "delay must be in 0 .. 100 000 us");
+  HIP_TRY(hipSetDevice(x->device));
+  hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, x->stream, (unsigned long long)(microseconds * 100.0));
+  HIP_TRY(hipGetLastError());
   return DQL_OK;
 }
 int dql_sync_time_ms(dql_ctx* x, double* avg_ms, int64_t* syncs) {

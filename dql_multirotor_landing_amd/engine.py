@@ -218,6 +218,9 @@ class Engine:
         _lib.check(self.lib.dql_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def delay(self, microseconds: float):
+        _lib.check(self.lib.dql_delay(self._h, float(microseconds)))
+
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.dql_set_option(self._h, name.encode(), int(value)))
 

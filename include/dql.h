@@ -245,6 +245,8 @@ int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, 
 /* average device duration of the fused step kernel over the launches made while the kernel timer was armed */
 int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
 int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
+/* holds the context's stream for this long (a one-wave timer kernel): phase offset between contexts that share a GPU */
+int dql_delay(dql_ctx* ctx, double microseconds);
 /* tuning knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup) */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 

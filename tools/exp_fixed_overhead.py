@@ -7,7 +7,7 @@ from dql_multirotor_landing_amd.config import DqlConfig, F32
 from dql_multirotor_landing_amd.engine import Engine
 for n in (4096, 1048576):
     for f_ag in (500.0, 100.0, 45.4545, 22.92):
-        e = Engine(DqlConfig(dtype=F32, f_ag=f_ag, t_max=2000.0), n, seed=1)
+        e = Engine(DqlConfig(dtype=F32, f_ag=f_ag, t_max=100.0), n, seed=1)
         e.train_steps(20, 1.0); e.sync()
         steps = 400 if n == 4096 else 60
         e.timer_start(); e.train_steps(steps, 1.0); ms = e.timer_stop()

@@ -15,7 +15,7 @@ from dql_multirotor_landing_amd.config import DqlConfig, F32
 from dql_multirotor_landing_amd.engine import Engine
 for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["4096", "65536"])]:
     for f_ag in (22.92, 500.0):
-        e = Engine(DqlConfig(dtype=F32, f_ag=f_ag, t_max=2000.0), n, seed=42)
+        e = Engine(DqlConfig(dtype=F32, f_ag=f_ag, t_max=100.0), n, seed=42)
         e.train_steps(100, 1.0); e.sync()
         K = 200
         e.episode_log_enable(K)
