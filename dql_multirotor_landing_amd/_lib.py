@@ -91,6 +91,8 @@ SYMBOLS = {
     "dql_episode_log_read": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "dql_discretise": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dql_manager_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _u64, _vp]),
+    "dql_place": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp]),

@@ -154,7 +154,7 @@ class DqlConfig:
     drone_bottom: float = 0.06  # half body_height (hummingbird.xacro:31)
     z_init: float = 4.0  # pkg/trainer.py:41
     init_sigma: float = 4.5 / 3  # pkg/landing_simulation_env.py:189
-    init_uniform: int = 0
+    init_uniform: int = 0  # 0: TrainingLandingEnv.reset (normal at level 0, else uniform); 1: always uniform; 2: SimulationLandingEnv.reset placement
     per_env_platform: int = 0
     goal_logic: int = 1  # 0 = SimulationMdp.check: no goal / success branch (pkg/mdp.py:784-845)
     fold_per_step: int = 0  # 1: one alpha step per launch towards the launch's mean target
@@ -208,7 +208,8 @@ def training_config(level: int = 0, **kw) -> DqlConfig:
 
 
 def simulation_config(**kw) -> DqlConfig:
-    """SimulationLandingEnv defaults (pkg/landing_simulation_env.py:285-306; pkg/mdp.py:580): level 4, v_z -0.4, uniform init."""
-    base = dict(working_curriculum_step=4, vz_setpoint=-0.4, init_uniform=1, z_init=4.0, goal_logic=0)
+    """SimulationLandingEnv defaults (pkg/landing_simulation_env.py:285-306; pkg/mdp.py:580): level 4, v_z -0.4, uniform start offset placed
+    as its reset() does (clip(platform - offset, +-p_max), :331-343; pinned by tests/golden G13), no goal / success branch in check()."""
+    base = dict(working_curriculum_step=4, vz_setpoint=-0.4, init_uniform=2, z_init=4.0, goal_logic=0)
     base.update(kw)
     return DqlConfig(**base)

@@ -580,6 +580,14 @@ template <typename T> DQL_DEV void make_B(T pitch_sp, T roll_sp, T (&B)[9]) {
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
 }
 
+// drone start coordinate along one axis from the random offset x0 and the platform coordinate (init_mode = cfg.init_uniform):
+// 0 / 1  TrainingLandingEnv.reset (pkg/landing_simulation_env.py:205-209): clip(x0 + mp, mp - p_max, mp + p_max)
+// 2      SimulationLandingEnv.reset (:339-343): clip(mp - x0, -p_max, p_max) — the offset is subtracted and the clip is absolute
+template <typename T> DQL_DEV T place_axis(int init_mode, T x0, T mp, T p_max) {
+  if (init_mode == 2) return clip(mp - x0, -p_max, p_max);
+  return clip(x0 + mp, mp - p_max, mp + p_max);
+}
+
 struct StepOut {  // what one env contributes to the shared tables / counters this period
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
   long long target_y_fx;
@@ -616,13 +624,13 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
     T x0;
     if (s.working == 0 && !s.init_uniform) { T n0, n1; box_muller(r[2], r[3], n0, n1); x0 = s.init_sigma * n0; }
     else x0 = fma_(T(2.0) * u24<T>(r[2]), s.p_max, -s.p_max);
-    e.p[0] = clip(x0 + e.mp_x, e.mp_x - s.p_max, e.mp_x + s.p_max);
+    e.p[0] = place_axis(s.init_uniform, x0, e.mp_x, s.p_max);
     e.p[1] = T(0.0); e.p[2] = s.z_init;
     if (two) {
       T y0;
       if (s.working == 0 && !s.init_uniform) { T n0, n1; box_muller(r2[2], r2[3], n0, n1); y0 = s.init_sigma * n0; }
       else y0 = fma_(T(2.0) * u24<T>(r2[2]), s.p_max, -s.p_max);
-      e.p[1] = clip(y0 + e.mp_y, e.mp_y - s.p_max, e.mp_y + s.p_max);
+      e.p[1] = place_axis(s.init_uniform, y0, e.mp_y, s.p_max);
     }
     e.v[0] = e.v[1] = e.v[2] = T(0.0); e.w[0] = e.w[1] = e.w[2] = T(0.0);
     e.q[0] = T(1.0); e.q[1] = e.q[2] = e.q[3] = T(0.0);

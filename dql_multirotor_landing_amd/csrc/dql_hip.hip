@@ -395,6 +395,33 @@ __global__ void k_mdp_transition(MdpK<T> c, long long n, uint32_t stages, const 
   ms[0 * n + i] = sp; ms[1 * n + i] = shp_p; ms[2 * n + i] = shp_v; ms[3 * n + i] = shp_a; ms[4 * n + i] = cum;
   ms[5 * n + i] = step_count; ms[6 * n + i] = cur_check; ms[7 * n + i] = code;
 }
+// the 100 Hz manager tick of the fused kernel (manager_states + manager_obs) replayed over scripted series, one lane per series
+template <typename T>
+__global__ void k_manager_run(SimK<T> c, long long n_series, long long n_ticks, const double* in, const uint8_t* contact, unsigned long long seed, double* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_series) return;
+  Env<T> e;
+  memset(&e, 0, sizeof(e));
+  e.kal_x_P = T(1.0); e.kal_y_P = T(1.0); e.mp_r = c.mp_r; e.mp_w = c.mp_w;
+  for (long long t = 0; t < n_ticks; ++t) {
+    const double* r = in + (i * n_ticks + t) * 14;
+    for (int k = 0; k < 3; ++k) { e.p[k] = (T)r[k]; e.v[k] = (T)r[3 + k]; }
+    for (int k = 0; k < 4; ++k) e.q[k] = (T)r[6 + k];
+    e.mp_x = (T)r[10]; e.mp_y = (T)r[11]; e.mp_u = (T)r[12]; e.mp_v = (T)r[13];
+    if (contact[i * n_ticks + t]) e.flags |= FL_CONTACT;
+    T R[9], cy, sy;
+    quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+    manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
+    manager_obs(c, e, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, (uint32_t)i, (uint32_t)t);
+    double* o = out + (i * n_ticks + t) * 12;
+    o[0] = e.obs_px; o[1] = e.obs_py; o[2] = e.obs_vx; o[3] = e.obs_vy; o[4] = e.obs_ax; o[5] = e.obs_ay;
+    o[6] = e.vz_state; o[7] = e.yw_state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;
+  }
+}
+template <typename T> __global__ void k_place(int init_mode, T p_max, const double* x0, const double* mp, long long n, double* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)place_axis(init_mode, (T)x0[i], (T)mp[i], p_max);
+}
 __global__ void k_predict(const double* qa, const double* qb, const int* idx, long long n, uint8_t* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
@@ -468,6 +495,7 @@ static int check_config(const dql_config* c) {
   if (c->pid_vz[2] != 0.0 || c->pid_yaw[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported by the fused kernel (reference launch files use Kd = 0)");
   if (c->manager_div < 1 || c->dt <= 0 || c->f_ag <= 0) return fail(DQL_EINVAL, "dt, f_ag, manager_div must be positive");
   if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
+  if (c->init_uniform < 0 || c->init_uniform > 2) return fail(DQL_EINVAL, "init_uniform must be 0 (normal at level 0, else uniform), 1 (uniform) or 2 (SimulationLandingEnv placement)");
   // step_count and curriculum_check are packed into 16 bits each (store_env): an episode must time out before they wrap
   if (!(c->t_max > 0) || c->t_max * c->f_ag >= 65535.0) return fail(DQL_EINVAL, "t_max * f_ag must be in (0, 65535): the per-env step counters are 16 bits wide");
   return DQL_OK;
@@ -1206,6 +1234,41 @@ int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t st
   HIP_TRY(hipMemcpy(idx_io, io.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(reward_out, ro.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(done_out, dn.p, (size_t)n, hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* in, const uint8_t* contact, uint64_t seed, double* out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n_series < 0 || n_ticks < 0 || ((n_series > 0 && n_ticks > 0) && (!in || !contact || !out))) return fail(DQL_EINVAL, "null array");
+  if (n_series == 0 || n_ticks == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, b, o;
+  const size_t cells = (size_t)n_series * (size_t)n_ticks;
+  UP(a, in, cells * 14 * sizeof(double)); UP(b, contact, cells);
+  if (o.alloc(cells * 12 * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  dql_config c2 = *cfg;
+  c2.two_axis = 1;  // the reference's estimator always runs on every axis; x-axis training configs simply never read y
+  const unsigned grid = (unsigned)((n_series + 63) / 64);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_manager_run<float>, dim3(grid), dim3(64), 0, 0, make_simk<float>(c2), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const uint8_t*)b.p, (unsigned long long)seed, (double*)o.p);
+  else hipLaunchKernelGGL(k_manager_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(c2), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const uint8_t*)b.p, (unsigned long long)seed, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, o.p, cells * 12 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 0 && (!x0 || !mp || !out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, b, o;
+  UP(a, x0, (size_t)n * sizeof(double)); UP(b, mp, (size_t)n * sizeof(double));
+  if (o.alloc((size_t)n * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_place<float>, dim3(grid), dim3(256), 0, 0, (int)cfg->init_uniform, (float)cfg->p_max, (const double*)a.p, (const double*)b.p, (long long)n, (double*)o.p);
+  else hipLaunchKernelGGL(k_place<double>, dim3(grid), dim3(256), 0, 0, (int)cfg->init_uniform, (double)cfg->p_max, (const double*)a.p, (const double*)b.p, (long long)n, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, o.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return DQL_OK;
 }
 

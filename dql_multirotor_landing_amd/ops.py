@@ -47,6 +47,29 @@ def mdp_transition(cfg: DqlConfig, action, obs, mdp_state, prev_idx, idx=None, s
     return ms, idx, rew, done
 
 
+def manager_run(cfg: DqlConfig, series, contact, seed: int = 0, device: int = 0) -> np.ndarray:
+    """The 100 Hz manager tick (ManagerNode.publish_obs + ObservationUtils) over scripted series: `series` [n_series][n_ticks][14]
+    (drone p, v, quaternion wxyz, platform x y u v), `contact` [n_series][n_ticks] -> [n_series][n_ticks][12] (include/dql.h)."""
+    a = _f64(series); c = np.ascontiguousarray(contact, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 14 or c.shape != a.shape[:2]:
+        raise ValueError("series must be [n_series][n_ticks][14], contact [n_series][n_ticks]")
+    out = np.zeros(a.shape[:2] + (12,))
+    cc = cfg.to_c()
+    _lib.check(_lib.load().dql_manager_run(C.byref(cc), device, a.shape[0], a.shape[1], _p(a), _p(c), int(seed), _p(out)))
+    return out
+
+
+def place(cfg: DqlConfig, x0, mp, device: int = 0) -> np.ndarray:
+    """Drone start coordinate for (random offset, platform coordinate) pairs: the reset placement selected by cfg.init_uniform."""
+    x0, mp = _f64(x0), _f64(mp)
+    if x0.shape != mp.shape or x0.ndim != 1:
+        raise ValueError("x0 and mp must be 1-D arrays of equal length")
+    out = np.zeros(len(x0))
+    cc = cfg.to_c()
+    _lib.check(_lib.load().dql_place(C.byref(cc), device, _p(x0), _p(mp), len(x0), _p(out)))
+    return out
+
+
 def agent_transfer(qa, qb, k: int, ratio: float, device: int = 0):
     """In-place DoubleQLearningAgent.transfer_learning on contiguous float64 tables of 2835 cells."""
     for t in (qa, qb):

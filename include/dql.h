@@ -109,7 +109,9 @@ typedef struct dql_config {
   double mp_top_z, mp_half_x, mp_half_y; /* landing surface 0.455, half extents 0.5 (+ drone half width) */
   double drone_bottom;          /* base box half height 0.06 */
   double z_init, init_sigma;    /* pkg/trainer.py:41 (4.0), p_max/3 (landing_simulation_env.py:189) */
-  int32_t init_uniform;         /* 0: N(0,sigma) at level 0 else U (TrainingLandingEnv.reset); 1: always U (Simulation env) */
+  int32_t init_uniform;         /* start offset x0 and placement: 0: x0 ~ N(0,sigma) at level 0 else U(-p_max, p_max), drone at clip(x0 + mp, mp +- p_max)
+                                   (TrainingLandingEnv.reset, pkg/landing_simulation_env.py:181-209); 1: always U, same placement; 2: always U,
+                                   drone at clip(mp - x0, +-p_max) as SimulationLandingEnv.reset has it (:331-343: offset subtracted, absolute clip) */
   int32_t per_env_platform;     /* 1: r_x, t_x drawn per env from the ranges below (BASELINE config 5) */
   int32_t goal_logic;           /* 1: TrainingMdp.check goal / success branch (pkg/mdp.py:402-425); 0: SimulationMdp.check (:784-845) */
   int32_t fold_per_step;        /* 0: per-visit fold (prod of (1-alpha) over the m visits of a launch); 1: ONE alpha step per launch towards the
@@ -275,6 +277,17 @@ int dql_discretise(const dql_config* cfg, int device, const double* rel_p, const
 enum { DQL_MDP_ACTION = 1, DQL_MDP_DISCRETISE = 2, DQL_MDP_CHECK = 4, DQL_MDP_REWARD = 8, DQL_MDP_SIMULATION = 16, DQL_MDP_ALL = 15 };
 int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t stages, const uint8_t* action, const double* obs,
                        double* mdp_state, const int32_t* prev_idx, int32_t* idx_io, double* reward_out, uint8_t* done_out);
+/* ManagerNode.publish_obs (scripts/manager_node.py:192-214, 292-310) + ObservationUtils.get_relative_state / get_observation
+ * (pkg/observation_utils.py:77-158) replayed for n_series independent scripted series of n_ticks 100 Hz ticks, with the
+ * device functions the fused step kernel runs.  in double[n_series][n_ticks][14] = drone p(3), v(3), quaternion w x y z (world
+ * frame), platform x y u v as reported at that tick; contact uint8[n_series][n_ticks]; out double[n_series][n_ticks][12] =
+ * observation p_x p_y v_x v_y a_x a_y, the v_z and yaw PID plant states, the platform set-point x y u v published by the tick.
+ * Noise (cfg noise_*_sd > 0) comes from the Philox stream of (seed, series). */
+int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* in, const uint8_t* contact,
+                    uint64_t seed, double* out);
+/* start coordinate of the drone along one axis for n (random offset x0, platform coordinate) pairs: the placement arithmetic of
+ * TrainingLandingEnv.reset / SimulationLandingEnv.reset selected by cfg->init_uniform (see dql_config) */
+int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:

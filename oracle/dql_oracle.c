@@ -629,6 +629,14 @@ static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL
   platform_update(s, e);
 }
 
+/* drone start coordinate along one axis from the random offset x0 and the platform coordinate (init_mode = cfg.init_uniform):
+ * 0 / 1  TrainingLandingEnv.reset (pkg/landing_simulation_env.py:205-209): clip(x0 + mp, mp - p_max, mp + p_max)
+ * 2      SimulationLandingEnv.reset (:339-343): clip(mp - x0, -p_max, p_max) — the offset is subtracted and the clip is absolute */
+static inline REAL place_axis(int init_mode, REAL x0, REAL mp, REAL p_max) {
+  if (init_mode == 2) return clip(mp - x0, -p_max, p_max);
+  return clip(x0 + mp, mp - p_max, mp + p_max);
+}
+
 typedef struct { int64_t decisions, episodes, by_code[DQL_N_CHECK_CODES], reward_fx; } ostats_t;
 
 /* One agent period for one env: pkg/trainer.py:191-212 body (guess, env.step, TD target) or, for an env whose
@@ -654,13 +662,13 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
     REAL x0;
     if (s->working == 0 && !s->init_uniform) { REAL n0, n1; box_muller(r[2], r[3], &n0, &n1); x0 = s->init_sigma * n0; }
     else x0 = FMA(R_(2.0) * u24(r[2]), s->p_max, -s->p_max);
-    e->p[0] = clip(x0 + e->mp_x, e->mp_x - s->p_max, e->mp_x + s->p_max);
+    e->p[0] = place_axis(s->init_uniform, x0, e->mp_x, s->p_max);
     e->p[1] = R_(0.0); e->p[2] = s->z_init;
     if (two) { /* the reference multiplies its y offset by 0 (B16); the 2-axis configs fly it */
       REAL y0;
       if (s->working == 0 && !s->init_uniform) { REAL n0, n1; box_muller(r2[2], r2[3], &n0, &n1); y0 = s->init_sigma * n0; }
       else y0 = FMA(R_(2.0) * u24(r2[2]), s->p_max, -s->p_max);
-      e->p[1] = clip(y0 + e->mp_y, e->mp_y - s->p_max, e->mp_y + s->p_max);
+      e->p[1] = place_axis(s->init_uniform, y0, e->mp_y, s->p_max);
     }
     e->v[0] = e->v[1] = e->v[2] = R_(0.0); e->w[0] = e->w[1] = e->w[2] = R_(0.0);
     e->q[0] = R_(1.0); e->q[1] = e->q[2] = e->q[3] = R_(0.0);
@@ -934,6 +942,34 @@ EXPORT void ORC(platform_run)(const dql_config* c, int64_t n, double* out) {
   env_t e; memset(&e, 0, sizeof(e));
   e.mp_r = s.mp_r; e.mp_w = s.mp_w;
   for (int64_t i = 0; i < n; ++i) { platform_update(&s, &e); out[i * 4] = e.mp_x; out[i * 4 + 1] = e.mp_y; out[i * 4 + 2] = e.mp_u; out[i * 4 + 3] = e.mp_v; }
+}
+/* the 100 Hz manager tick (scripts/manager_node.py:192-214,292-310 + pkg/observation_utils.py:77-158) replayed over a scripted
+ * series: per tick in[14] = drone p(3), v(3), quaternion w x y z (world frame), platform x y u v as Gazebo reports them at this
+ * tick; contact[t] = bumper flag.  out[11] = obs p_x p_y v_x v_y a_x a_y, v_z plant state, yaw plant state, then the platform
+ * set-point x y u v published by this tick.  The acceleration estimator runs on both axes (two_axis forced on). */
+EXPORT void ORC(manager_run)(const dql_config* c, int64_t n_ticks, const double* in /*[n_ticks][14]*/, const uint8_t* contact, uint64_t seed,
+                             double* out /*[n_ticks][12]*/) {
+  simc_t s; simc_init(&s, c);
+  s.two_axis = 1;
+  env_t e; memset(&e, 0, sizeof(e));
+  e.kal_P[0] = e.kal_P[1] = R_(1.0);
+  e.mp_r = s.mp_r; e.mp_w = s.mp_w;
+  for (int64_t t = 0; t < n_ticks; ++t) {
+    const double* r = in + t * 14;
+    for (int k = 0; k < 3; ++k) { e.p[k] = (REAL)r[k]; e.v[k] = (REAL)r[3 + k]; }
+    for (int k = 0; k < 4; ++k) e.q[k] = (REAL)r[6 + k];
+    e.mp_x = (REAL)r[10]; e.mp_y = (REAL)r[11]; e.mp_u = (REAL)r[12]; e.mp_v = (REAL)r[13];
+    if (contact[t]) e.flags |= FL_CONTACT;
+    REAL R[9], cy, sy;
+    quat_to_R(e.q, R); yaw_cs(R, &cy, &sy);
+    manager_tick(&s, &e, R, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, 0u, (uint32_t)t);
+    double* o = out + t * 12;
+    o[0] = e.obs[0]; o[1] = e.obs[1]; o[2] = e.obs[2]; o[3] = e.obs[3]; o[4] = e.obs[4]; o[5] = e.obs[5];
+    o[6] = e.vz.state; o[7] = e.yaw.state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;
+  }
+}
+EXPORT void ORC(place)(const dql_config* c, const double* x0, const double* mp, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = (double)place_axis(c->init_uniform, (REAL)x0[i], (REAL)mp[i], (REAL)c->p_max);
 }
 EXPORT void ORC(det_math)(const double* x, const double* y, int64_t n, double* s, double* c, double* at2, double* lg) {
   for (int64_t i = 0; i < n; ++i) {

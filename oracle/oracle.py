@@ -345,3 +345,20 @@ def det_math(x, y, dtype=1):
     s = np.zeros_like(x); c = np.zeros_like(x); a = np.zeros_like(x); lg = np.zeros_like(x)
     _run("det_math", dtype, _p(x), _p(y), C.c_int64(len(x)), _p(s), _p(c), _p(a), _p(lg))
     return s, c, a, lg
+
+
+def manager_run(cfg: DqlConfig, series, contact, seed=0, dtype=None):
+    """one series [n_ticks][14] -> [n_ticks][12] (see dql_oracle.c manager_run)"""
+    a = _f64(series); c = np.ascontiguousarray(contact, dtype=np.uint8)
+    out = np.zeros((a.shape[0], 12))
+    cc = cfg.to_c()
+    _run("manager_run", cfg.dtype if dtype is None else dtype, C.byref(cc), C.c_int64(a.shape[0]), _p(a), _p(c), C.c_uint64(int(seed)), _p(out))
+    return out
+
+
+def place(cfg: DqlConfig, x0, mp, dtype=None):
+    x0, mp = _f64(x0), _f64(mp)
+    out = np.zeros(len(x0))
+    cc = cfg.to_c()
+    _run("place", cfg.dtype if dtype is None else dtype, C.byref(cc), _p(x0), _p(mp), C.c_int64(len(x0)), _p(out))
+    return out

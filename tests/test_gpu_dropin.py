@@ -235,3 +235,49 @@ def test_sharded_trainer_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     assert strip(out["history"]) == h1 and [h["level"] for h in h1] == [0, 1, 2]
     for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):
         assert np.array_equal(np.load(tmp_path / "two" / f), np.load(tmp_path / "one" / f))
+
+
+def test_g13_reference_env_outputs_through_the_hip_engine(golden_dir):
+    """a17-a19 on the GPU: the fixture's fake Gazebo played back a flight of this simulator to the REFERENCE's TrainingLandingEnv /
+    SimulationLandingEnv; here the HIP engine (one env, float64, same seed and actions) flies it again: identical signals, and per
+    agent period the reference env's returned state / reward / done / CheckResult == the fused step's."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle_golden import G13_CASES, _g13_check, _g13_fly
+    from dql_multirotor_landing_amd.engine import Engine
+    z = np.load(golden_dir / "g13_env.npz")
+    for tag in G13_CASES:
+        sig, res = _g13_fly(Engine, tag, z)
+        _g13_check(tag, z, sig, res)
+
+
+def test_g13_dropin_env_classes_return_what_the_reference_env_returned(golden_dir):
+    """The drop-in TrainingLandingEnv / SimulationLandingEnv (same constructor arguments, same reset() / step() protocol) on the
+    fixture's seed and actions return, call by call, what the reference's classes returned."""
+    from dql_multirotor_landing_amd.landing_simulation_env import SimulationLandingEnv, TrainingLandingEnv
+    z = np.load(golden_dir / "g13_env.npz")
+    for tag, cls, level, t_max, seed in (("train0", TrainingLandingEnv, 0, 4, 1300), ("train2", TrainingLandingEnv, 2, 4, 1302), ("sim4", SimulationLandingEnv, 4, 6, 1304)):
+        rows, actions = z[f"{tag}_rows"], z[f"{tag}_actions"]
+        env = cls(level, t_max=t_max, z_init=4.0, seed=seed)
+        i = 0
+        while i < len(rows):
+            assert rows[i, 0] == 0
+            s = env.reset()
+            if cls is TrainingLandingEnv:
+                assert tuple(s) == tuple(int(v) for v in rows[i, 2:7])
+            else:
+                assert tuple(s[0]) == tuple(int(v) for v in rows[i, 2:7]) and tuple(s[1]) == tuple(int(v) for v in rows[i, 7:12])
+            i += 1
+            while i < len(rows) and rows[i, 0] == 1:
+                if cls is TrainingLandingEnv:
+                    st, r, done, info = env.step(int(actions[i]))
+                    assert tuple(st) == tuple(int(v) for v in rows[i, 2:7]) and r == rows[i, 12] and done == bool(rows[i, 13])
+                    assert info["Current reward"] == r and (("Termination condition" in info) == done)
+                else:
+                    sx, sy, done, info = env.step(int(actions[i]), 2)
+                    assert tuple(sx) == tuple(int(v) for v in rows[i, 2:7]) and tuple(sy) == tuple(int(v) for v in rows[i, 7:12]) and done == bool(rows[i, 13])
+                i += 1
+                if done:
+                    break
+        env.close()

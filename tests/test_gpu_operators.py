@@ -61,3 +61,49 @@ def test_agent_golden(ops, golden_dir):
     assert not qb.any()
     A = np.load(golden_dir / "assets" / "Q_table_a.npy"); B = np.load(golden_dir / "assets" / "Q_table_b.npy")
     np.testing.assert_array_equal(ops.agent_predict(A, B, np.arange(945)), g["predict_actions"])
+
+
+# ---- G12: the manager tick of the fused kernel (manager_states + manager_obs) through dql_manager_run ----
+def test_manager_run_golden_and_oracle(ops, golden_dir):
+    """a20 on the GPU: the device functions of the fused step's 100 Hz manager tick, replayed over the reference's scripted series:
+    == the oracle bit for bit (float64 and float32), and == ManagerNode.publish_obs / ObservationUtils within the tolerances of
+    tests/test_oracle_golden.py (rotation helpers of tf are stand-ins there); quirk B19 reproduced from reference output."""
+    from dql_multirotor_landing_amd.config import F32, Q_FROZEN_ACC_REFERENCE, Q_REFERENCE
+    from oracle import oracle as orc
+    z = np.load(golden_dir / "g12_manager.npz")
+    for tag in ("a_noise0", "b_noise", "c_yaw"):
+        sd = z[f"{tag}_noise_sd"]
+        for dtype in (F64, F32):
+            cfg = DqlConfig(dtype=dtype, two_axis=1, noise_pos_sd=float(sd[0]), noise_vel_sd=float(sd[1]))
+            got = ops.manager_run(cfg, z[f"{tag}_in"][None], z[f"{tag}_contact"][None], seed=5)[0]
+            # the series index keys the noise stream: series 0 here == env id 0 in the oracle's replay
+            want = orc.manager_run(cfg, z[f"{tag}_in"], z[f"{tag}_contact"], seed=5)
+            np.testing.assert_array_equal(got, want, err_msg=f"{tag} dtype {dtype}: HIP != oracle")
+        ref = z[f"{tag}_out"]
+        got = ops.manager_run(DqlConfig(dtype=F64, two_axis=1, noise_pos_sd=float(sd[0]), noise_vel_sd=float(sd[1])), z[f"{tag}_in"][None], z[f"{tag}_contact"][None])[0]
+        np.testing.assert_allclose(got[:, 4:6], ref[:, 4:6], rtol=1e-9, atol=2e-10)      # acceleration: clean velocity, Kalman R = sd^2, B19
+        np.testing.assert_allclose(got[:, 6], ref[:, 6], rtol=0, atol=0)                  # v_z plant state
+        np.testing.assert_allclose(got[:, 7], ref[:, 7], rtol=0, atol=1e-12)              # yaw plant state
+        np.testing.assert_allclose(got[:, 8:], ref[:, 8:], rtol=0, atol=1e-11)            # platform set-point published by the tick
+        if sd[0] == 0:
+            np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=0, atol=2e-12)
+    rel = z["a_noise0_rel"]
+    i = np.arange(1, len(rel))
+    got = ops.manager_run(DqlConfig(dtype=F64, two_axis=1), z["a_noise0_in"][None], z["a_noise0_contact"][None])[0]
+    np.testing.assert_allclose(got[1:, 4], (rel[1:, 3] - rel[0, 3]) / (0.01 * i), rtol=1e-9, atol=1e-10)   # B19: frozen reference sample
+    paper = ops.manager_run(DqlConfig(dtype=F64, two_axis=1, quirks=Q_REFERENCE & ~Q_FROZEN_ACC_REFERENCE), z["a_noise0_in"][None], z["a_noise0_contact"][None])[0]
+    np.testing.assert_allclose(paper[1:, 4], np.diff(rel[:, 3]) / 0.01, rtol=1e-9, atol=1e-9)
+    # several series at once: one lane each, own noise stream each
+    many = ops.manager_run(DqlConfig(dtype=F64, two_axis=1, noise_pos_sd=0.25, noise_vel_sd=0.1), np.repeat(z["b_noise_in"][None], 70, axis=0),
+                           np.repeat(z["b_noise_contact"][None], 70, axis=0), seed=9)
+    assert many.shape == (70, 300, 12) and np.array_equal(many[:, :, 4:6], np.repeat(many[:1, :, 4:6], 70, axis=0)) and not np.array_equal(many[0, :, 0], many[1, :, 0])
+
+
+def test_place_golden(ops, golden_dir):
+    """a17 / a19 placement arithmetic of reset() on the GPU == what the reference's reset() handed to /gazebo/set_model_state."""
+    z = np.load(golden_dir / "g13_env.npz")
+    for tag, mode in (("train0", 0), ("train2", 0), ("sim4", 2)):
+        pl = z[f"{tag}_placements"]
+        np.testing.assert_array_equal(ops.place(DqlConfig(dtype=F64, init_uniform=mode), pl[:, 0], pl[:, 2]), pl[:, 3])
+    with pytest.raises(ValueError):
+        ops.place(DqlConfig(init_uniform=3), [0.0], [0.0])

@@ -189,3 +189,151 @@ def test_g7_npy_layout(golden_dir):
         hdr = bytes.fromhex(meta[name]["header_hex"])
         assert hdr[:6] == b"\x93NUMPY" and hdr[6:8] == b"\x01\x00"
         assert b"'descr': '<f8', 'fortran_order': False, 'shape': (5, 3, 3, 3, 7, 3), }" in hdr
+
+
+# ---- G12: the 100 Hz manager tick (ManagerNode.publish_obs + ObservationUtils), pins a20 and quirk B19 ----
+def _g12_cfg(noise_sd, quirks=None):
+    from dql_multirotor_landing_amd.config import Q_REFERENCE
+    return DqlConfig(dtype=F64, two_axis=1, noise_pos_sd=float(noise_sd[0]), noise_vel_sd=float(noise_sd[1]), quirks=Q_REFERENCE if quirks is None else quirks)
+
+
+def test_g12_manager_tick_matches_reference(golden_dir):
+    """What one manager tick publishes, against the reference's own ManagerNode.publish_obs over 300 scripted ticks: relative
+    position / velocity = platform - drone in the yaw-only frame, acceleration through the Kalman filter from the UN-noised
+    velocity, PID plant states (v_z = -rel_v_z, yaw of q_drone q_platform^-1), and the platform set-point published by the SAME
+    tick (the observation still sees the previous one).  Tolerances: the rotation helpers on the reference side are stand-ins
+    for tf (as in G9) and the frame rotation is a Newton 1/sqrt here, so 1e-12 instead of bit equality."""
+    z = np.load(golden_dir / "g12_manager.npz")
+    for tag in ("a_noise0", "c_yaw"):
+        got = orc.manager_run(_g12_cfg(z[f"{tag}_noise_sd"]), z[f"{tag}_in"], z[f"{tag}_contact"])
+        ref = z[f"{tag}_out"]
+        np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=0, atol=2e-12, err_msg=tag + " p / v")
+        np.testing.assert_allclose(got[:, 4:6], ref[:, 4:6], rtol=1e-9, atol=2e-10, err_msg=tag + " acceleration")   # (v - v0) / dt: cancellation
+        np.testing.assert_allclose(got[:, 6], ref[:, 6], rtol=0, atol=0, err_msg=tag + " v_z plant state")
+        np.testing.assert_allclose(got[:, 7], ref[:, 7], rtol=0, atol=1e-12, err_msg=tag + " yaw plant state")
+        np.testing.assert_allclose(got[:, 8:], ref[:, 8:], rtol=0, atol=1e-11, err_msg=tag + " platform set-point")  # G11's tolerance
+    # the published set-point is NOT what this tick's observation used: rel_p_x = (platform as reported) - drone
+    a_in, a_out = z["a_noise0_in"], z["a_noise0_out"]
+    np.testing.assert_allclose(a_out[:, 0], a_in[:, 10] - a_in[:, 0], rtol=0, atol=1e-15)
+    assert np.abs(a_out[:, 8] - a_in[:, 10]).max() > 1e-5  # the fresh set-point differs (by the extrapolation error) and is not what was observed
+
+
+def test_g12_quirk_b19_frozen_acceleration_reference(golden_dir):
+    """B19, asserted from REFERENCE OUTPUT: ObservationUtils sets last_velocity / last_timestep on its first call and never again
+    (pkg/observation_utils.py:137-150), so rel_a = (v_i - v_0) / (t_i - t_0) — the mean acceleration since the node started —
+    not the finite difference of successive samples.  The oracle reproduces it with the quirk bit and departs without."""
+    from dql_multirotor_landing_amd.config import Q_FROZEN_ACC_REFERENCE, Q_REFERENCE
+    z = np.load(golden_dir / "g12_manager.npz")
+    rel, out = z["a_noise0_rel"], z["a_noise0_out"]
+    i = np.arange(1, len(rel))
+    frozen = (rel[1:, 3] - rel[0, 3]) / (0.01 * i)
+    np.testing.assert_allclose(out[1:, 4], frozen, rtol=1e-15, atol=0)   # R = 0: the filter passes it through as x + 1 * (z - x), one rounding
+    successive = np.diff(rel[:, 3]) / 0.01
+    assert np.abs(out[1:, 4] - successive)[50:].mean() > 0.05            # and clearly not a per-tick finite difference
+    assert out[0, 4] == 0.0
+    paper = orc.manager_run(_g12_cfg(z["a_noise0_noise_sd"], quirks=Q_REFERENCE & ~Q_FROZEN_ACC_REFERENCE), z["a_noise0_in"], z["a_noise0_contact"])
+    np.testing.assert_allclose(paper[1:, 4], successive, rtol=1e-9, atol=1e-9)
+
+
+def test_g12_noise_feeds_the_message_not_the_filter(golden_dir):
+    """With observation noise (0.25 m, 0.1 m/s: the code defaults, scripts/manager_node.py:83-88) the reference adds N(0, sd) to the
+    published position and velocity only; the acceleration estimate runs on the clean velocity with R = sd_v^2
+    (pkg/filters.py:49) — so rel_a is deterministic and must match to rounding, while the noise itself is compared in distribution."""
+    z = np.load(golden_dir / "g12_manager.npz")
+    sd = z["b_noise_noise_sd"]
+    got = orc.manager_run(_g12_cfg(sd), z["b_noise_in"], z["b_noise_contact"], seed=5)
+    np.testing.assert_allclose(got[:, 4:6], z["b_noise_out"][:, 4:6], rtol=1e-9, atol=1e-10)
+    ref_noise = z["b_noise_noise"]
+    assert abs(ref_noise[:, 0].std() / sd[0] - 1) < 0.15 and abs(ref_noise[:, 3].std() / sd[1] - 1) < 0.15
+    mine_p = (got[:, 0] - z["b_noise_rel"][:, 0]) / sd[0]; mine_v = (got[:, 2] - z["b_noise_rel"][:, 3]) / sd[1]
+    for m in (mine_p, mine_v):
+        assert abs(m.std() - 1) < 0.15 and abs(m.mean()) < 0.2
+    assert abs(np.corrcoef(mine_p, mine_v)[0, 1]) < 0.2
+
+
+# ---- G13: TrainingLandingEnv / SimulationLandingEnv reset() and step() against a fake Gazebo playing back a recorded flight ----
+G13_CASES = {"train0": dict(working_curriculum_step=0, t_max=4.0), "train2": dict(working_curriculum_step=2, t_max=4.0),
+             "sim4": dict(working_curriculum_step=4, t_max=6.0, vz_setpoint=-0.4, init_uniform=2, goal_logic=0, z_init=4.0)}
+G13_SEED = {"train0": 1300, "train2": 1302, "sim4": 1304}
+
+
+def _g13_fly(engine_cls, tag, z):
+    """this build's simulator (oracle or HIP engine, float64, one env) on the fixture's seed and actions -> per-period signals + outputs"""
+    o = engine_cls(DqlConfig(dtype=F64, **G13_CASES[tag]), 1, seed=G13_SEED[tag])
+    names, inames = o.field_names(), o.field_names(True)
+    sig, res = [], []
+    for a in z[f"{tag}_actions"]:
+        o.step(np.array([a], dtype=np.uint8))
+        reals, ints = o.get_fields()
+        g = lambda k: float(reals[names.index(k)][0]); gi = lambda k: int(ints[inames.index(k)][0])
+        sig.append([g("obs_p_x"), g("obs_p_y"), g("obs_v_x"), g("obs_v_y"), g("obs_a_x"), g("obs_a_y"), g("qw"), g("qx"), g("qy"), g("qz"), g("pz"),
+                    float(bool(gi("flags") & 16))])
+        res.append([float(bool(gi("flags") & 8)), float(bool(gi("flags") & 1)), gi("idx_x"), gi("code"), g("reward"), g("pitch_sp")])
+    return np.array(sig), np.array(res)
+
+
+def _g13_check(tag, z, sig, res):
+    # (1) the played-back flight IS this simulator's flight (if this fails after a deliberate arithmetic change: regenerate the fixture)
+    rec = np.column_stack([z[f"{tag}_rec_obs"], z[f"{tag}_rec_quat"], z[f"{tag}_rec_z"], z[f"{tag}_rec_contact"]])
+    np.testing.assert_array_equal(sig, rec, err_msg="simulator signals differ from the recorded flight: regenerate tests/golden (make_golden.py)")
+    np.testing.assert_array_equal(res, z[f"{tag}_sim"])
+    # (2) what the reference's env.reset() / env.step() returned for those signals == what the fused step produced
+    rows = z[f"{tag}_rows"]
+    pack = lambda t: int((((t[0] * 3 + t[1]) * 3 + t[2]) * 3 + t[3]) * 7 + t[4])
+    assert len(rows) == len(res)
+    for r, s in zip(rows, res):
+        assert pack(r[2:7]) == int(s[2])                       # discrete state
+        assert bool(r[0] == 0) == bool(s[0])                   # reset periods line up
+        if r[0] == 1:
+            assert bool(r[13]) == bool(s[1])                   # done <=> "Termination condition" in info
+            if tag != "sim4":
+                assert r[12] == s[4]                           # reward, float64 ==
+                assert int(r[14]) == int(s[3])                 # CheckResult
+    assert rows[:, 13].sum() >= 3, "the script must contain several terminated episodes"
+
+
+def test_g13_env_reset_step_sequencing_and_outputs(golden_dir):
+    """a17-a19: the reference's env classes, driven by a fake Gazebo that plays back a flight of THIS simulator, return per agent
+    period exactly what the fused step computes (state index, reward, done, CheckResult), reset periods included; their service /
+    topic call order is the one the fused kernel's period follows (set-point first, then one agent period of simulation, then
+    the fresh pose + the latest latched observation)."""
+    import json
+    z = np.load(golden_dir / "g13_env.npz")
+    for tag in G13_CASES:
+        sig, res = _g13_fly(orc.Oracle, tag, z)
+        _g13_check(tag, z, sig, res)
+    calls = json.loads((golden_dir / "g13_env_calls.json").read_text())
+    for tag in G13_CASES:
+        assert calls[tag]["reset_calls"] == ["srv:pause_physics", "srv:get_model_state:moving_platform", "srv:set_model_state", "pub:reset_simulation",
+                                             "srv:unpause_physics", "sleep", "srv:pause_physics", "srv:get_model_state:hummingbird"]
+        assert calls[tag]["step_calls"] == ["pub:action_to_interface", "srv:unpause_physics", "sleep", "srv:pause_physics", "srv:get_model_state:hummingbird"]
+
+
+def test_g13_reset_placement_arithmetic(golden_dir):
+    """TrainingLandingEnv.reset places the drone at clip(x0 + mp_x, mp_x +- p_max) (x0 ~ N(0, p_max / 3) at level 0, U(-p_max, p_max)
+    above), y = 0, z = z_init; SimulationLandingEnv.reset at clip(mp_x - x0, +-p_max) with its y offset multiplied by 0 (B16).
+    Same arithmetic in the simulator's reset (init_uniform 0 / 2), bit for bit."""
+    z = np.load(golden_dir / "g13_env.npz")
+    for tag, mode in (("train0", 0), ("train2", 0), ("sim4", 2)):
+        pl = z[f"{tag}_placements"]   # x0, y0, platform x, placed x, y, z
+        got = orc.place(DqlConfig(dtype=F64, init_uniform=mode), pl[:, 0], pl[:, 2])
+        np.testing.assert_array_equal(got, pl[:, 3])
+        assert (pl[:, 4] == 0).all() and (pl[:, 5] == 4.0).all()
+    pl = z["sim4_placements"]
+    assert (np.abs(pl[:, 3]) <= 4.5).all() and np.abs(pl[:, 3] - (pl[:, 2] - pl[:, 0])).min() == 0.0
+    # the absolute clip is reached by construction in some draw of a longer series
+    x0 = np.linspace(-4.5, 4.5, 19); mp = np.full(19, 1.9)
+    got = orc.place(DqlConfig(dtype=F64, init_uniform=2), x0, mp)
+    np.testing.assert_array_equal(got, np.clip(mp - x0, -4.5, 4.5))
+    assert (got == 4.5).any()
+
+
+def test_g13_simulation_env_y_state(golden_dir):
+    """SimulationLandingEnv returns a second tuple for the y axis, discretised from rel_*_y and ROLL (pkg/mdp.py:625-782); the
+    reference never flies y (B16), so it is the state of a drone sitting at y = 0: reproduced from the recorded signals."""
+    z = np.load(golden_dir / "g13_env.npz")
+    rows, obs, q = z["sim4_rows"], z["sim4_rec_obs"], z["sim4_rec_quat"]
+    roll = np.arctan2(2 * (q[:, 2] * q[:, 3] + q[:, 0] * q[:, 1]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))
+    idx = orc.discretise(DqlConfig(dtype=F64, working_curriculum_step=4), obs[:, 1], obs[:, 3], obs[:, 5], roll)
+    sy = rows[:, 7:12].astype(int)
+    np.testing.assert_array_equal(idx, (((sy[:, 0] * 3 + sy[:, 1]) * 3 + sy[:, 2]) * 3 + sy[:, 3]) * 7 + sy[:, 4])
