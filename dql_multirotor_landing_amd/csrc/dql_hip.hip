@@ -156,6 +156,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
   return q;
 }
 
+#define DQL_MAX_PERIODS 4  // agent periods one launch may run back to back per env (option "periods_per_launch")
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T>* mdp;
@@ -168,11 +169,13 @@ template <typename T> struct StepArgs {
   FoldK fold;
   StatsDev* stats;
   const uint8_t* actions;
-  unsigned long long* elog;            // episode log row of this launch or null: [n_waves] done masks, [n_waves] success masks
-  long long n, env_id_offset, step_index, g0;
+  unsigned long long* elog;            // episode log rows of this launch or null: per period [n_waves] done masks, [n_waves] success masks
+  long long n, env_id_offset, step_index;  // step_index: the first agent period of this launch
+  long long g0[DQL_MAX_PERIODS];           // physics ticks elapsed before each period of the launch
   unsigned long long seed;
   double eps;
-  int mode, n_ticks, env_blocks, have_prev, windowed;
+  int n_ticks[DQL_MAX_PERIODS];
+  int mode, n_periods, env_blocks, have_prev, windowed;
 };
 
 // wave64 sum on the DPP path (no LDS permutes, no waits): row_shr 1, 2, 4, 8 build the prefix sums of each row of 16 lanes,
@@ -202,14 +205,19 @@ DQL_DEV long long wave_sum(long long v) {
 template <int BYTES> DQL_DEV void warm_kernarg() {
   const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
   unsigned t0, t1, t2, t3, t4, t5, t6, t7;
-  static_assert(BYTES > 0x1c0 && BYTES <= 12 * 64, "adjust the touch list to the argument size");
   asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
                "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
                "s_waitcnt lgkmcnt(0)"
                : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(p));
-  if constexpr (BYTES > 0x2c0)  // double-precision constants: four more lines
-    asm volatile("s_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+  // the remaining lines, only those the arguments reach; loads and their wait stay inside ONE asm statement (the compiler must
+  // not reuse a destination register while a load into it is still in flight)
+  static_assert((BYTES > 0x200 && BYTES <= 0x240) || (BYTES > 0x300 && BYTES <= 0x340), "adjust the touch list to the argument size");
+  if constexpr (BYTES <= 0x240)
+    asm volatile("s_load_dword %0, %1, 0x200\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0) : "s"(p));
+  else
+    asm volatile("s_load_dword %0, %5, 0x200\n\ts_load_dword %1, %5, 0x240\n\ts_load_dword %2, %5, 0x280\n\ts_load_dword %3, %5, 0x2c0\n\t"
+                 "s_load_dword %4, %5, 0x300\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) : "s"(p));
 }
 // LONE: the register-hungry layout (per-tick constants in VGPRs, tick loop laid out per manager period: dql_device.hpp,
 // agent_period) for batches of at most a couple of waves per SIMD.  Every instantiation is capped at 2 waves per SIMD: measured
@@ -253,43 +261,55 @@ template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) 
 #ifdef DQL_WAVE_CLOCK
   unsigned long long clk1 = 0;
 #endif
+  // P agent periods per launch (option "periods_per_launch", default 1): the env stays in registers between them, so the state
+  // round trip through HBM, the launch boundary and the table-writer work are paid once per P periods; the acting tables are
+  // those of the launch for all P periods, every period's TD targets go to the launch's accumulators
+  Env<T> e;
   if (i < a.n) {
-    Env<T> e;
     // the packed ints go first: their state index addresses the acting-table row, whose request then rides along with the
     // state quads instead of waiting for them (one memory round trip less at the head of the wave)
     const int4 iv = a.si[i];
-    // a fresh or reset env has no previous state (idx -1): its row is never used, but the address must stay inside the table
-    const QRow qx = load_qrow(a.qa, a.qb, (unsigned)iv.x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? iv.x : 0);
     load_env(e, a.sr, iv, a.n, i, a.c);
     DQL_MARK_T(e, 2);
-    const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-    const StepOut o = agent_period<LONE>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index, a.g0, a.n_ticks);
-    if (STAGED) {
-      store_env(e, a.sr, a.si, a.n, i, a.c);
-      if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
-      if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
-    } else {  // the atomics go out first: their round trip hides behind the state stores
-      // global layout [4][N_CELLS]: a staged index in table b's half sits another N_CELLS further on
-      if (o.cell >= 0) { const int g = o.cell + (o.cell >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
-      if (o.cell_y >= 0) { const int g = o.cell_y + (o.cell_y >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
-      store_env(e, a.sr, a.si, a.n, i, a.c);
+  }
+  long long dec_w = 0, don_w = 0, rfx_w = 0;  // per-wave totals over the periods of this launch (wave-uniform after the reductions)
+  for (int p = 0; p < a.n_periods; ++p) {
+    dec = 0; don = 0; rfx = 0; goal = false;
+    if (i < a.n) {
+      // a fresh or reset env has no previous state (idx -1): its row is never used, but the address must stay inside the table
+      const QRow qx = load_qrow(a.qa, a.qb, (unsigned)e.idx_x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? e.idx_x : 0);
+      const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
+      const StepOut o = agent_period<LONE>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
+      if (STAGED) {
+        if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
+        if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
+      } else {
+        // global layout [4][N_CELLS]: a staged index in table b's half sits another N_CELLS further on
+        if (o.cell >= 0) { const int g = o.cell + (o.cell >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
+        if (o.cell_y >= 0) { const int g = o.cell_y + (o.cell_y >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
+      }
+      dec = o.decision; don = o.done; rfx = o.reward_fx;
+      if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
     }
-    dec = o.decision; don = o.done; rfx = o.reward_fx;
-    if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
+#ifndef DQL_WAVE_CLOCK
+    if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
+      const unsigned long long dm = __ballot(don != 0), sm = __ballot(goal);
+      const long long w = i >> 6, nw = (a.n + 63) >> 6;
+      unsigned long long* row = a.elog + (size_t)p * 2 * (size_t)nw;
+      if ((tid & 63) == 0 && w < nw) { row[w] = dm; row[nw + w] = sm; }
+    }
+#endif
+    // wave64 shuffle reductions -> per-wave totals
+    dec_w += __popcll(__ballot(dec != 0)); don_w += __popcll(__ballot(don != 0)); rfx_w += wave_sum(rfx);
+  }
+  if (i < a.n) {
+    store_env(e, a.sr, a.si, a.n, i, a.c);  // the atomics went out first: their round trip hides behind the state stores
     DQL_MARK_T(e, 6);
 #ifdef DQL_WAVE_CLOCK
     clk1 = e.mark;
 #endif
   }
-#ifndef DQL_WAVE_CLOCK
-  if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
-    const unsigned long long dm = __ballot(don != 0), sm = __ballot(goal);
-    const long long w = i >> 6, nw = (a.n + 63) >> 6;
-    if ((tid & 63) == 0 && w < nw) { a.elog[w] = dm; a.elog[nw + w] = sm; }
-  }
-#endif
-  // wave64 shuffle reductions -> one atomic per wave (LDS when staged, then one global atomic per workgroup)
-  dec = __popcll(__ballot(dec != 0)); don = __popcll(__ballot(don != 0)); rfx = wave_sum(rfx);
+  dec = dec_w; don = don_w; rfx = rfx_w;
   if (STAGED) {
     if ((tid & 63) == 0) {
       if (dec) atomicAdd(&sStat[0], (unsigned long long)dec);
@@ -467,8 +487,11 @@ struct dql_ctx {
   double* alpha_tab = nullptr; int n_tab = 0;
   StatsDev* stats = nullptr;
   long long step_index = 0;      // agent periods launched so far (the tick schedule is a pure function of it)
+  long long launch_index = 0;    // launches so far: its parity selects the ping-pong buffers (a launch may cover several periods)
+  int periods_per_launch = 1;    // option "periods_per_launch"
+  int pending_periods = 1;       // agent periods the pending accumulators cover (learning-rate steps of a per-step fold)
   long long stats_step_base = 0;
-  bool pending = false;          // acc[(step_index + 1) & 1] holds the last launch's accumulators, not yet folded into the master tables
+  bool pending = false;          // acc[(launch_index + 1) & 1] holds the last launch's accumulators, not yet folded into the master tables
   uint8_t* d_actions = nullptr;
   void* mdpk = nullptr;  // MdpK<T> in device memory
   hipStream_t stream = nullptr;
@@ -524,58 +547,61 @@ template <typename T> static int launch_init(dql_ctx* x) {
 static FoldK make_foldk(const dql_ctx* x, long long n_launch = 1) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step, n_launch}; }
 static long long ticks_before(const dql_ctx* x, long long j) { return (long long)std::floor((double)j * (1.0 / (x->cfg.f_ag * x->cfg.dt))); }
 
-template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, double eps, int envs_per_block) {
-  const long long j = x->step_index;
+template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, double eps, int envs_per_block, int n_periods) {
+  const long long j = x->step_index, l = x->launch_index;
   StepArgs<T> a;
   a.c = make_simk<T>(x->cfg);
   a.mdp = (const MdpK<T>*)x->mdpk;
   a.sr = (Quad<T>*)x->sr; a.si = x->si;
-  a.qa = x->tb[j & 1]; a.qb = x->tbb[j & 1]; a.acc_cur = (unsigned long long*)x->acc[j & 1];
-  a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(j + 1) & 1]; a.qb_pub = x->tbb[(j + 1) & 1];
-  a.acc_prev = x->acc[(j + 1) & 1]; a.window = x->window;
-  a.fold = make_foldk(x); a.stats = x->stats; a.actions = x->ext_actions ? x->ext_actions : x->d_actions;
+  a.qa = x->tb[l & 1]; a.qb = x->tbb[l & 1]; a.acc_cur = (unsigned long long*)x->acc[l & 1];
+  a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(l + 1) & 1]; a.qb_pub = x->tbb[(l + 1) & 1];
+  a.acc_prev = x->acc[(l + 1) & 1]; a.window = x->window;
+  a.fold = make_foldk(x, x->pending_periods); a.stats = x->stats; a.actions = x->ext_actions ? x->ext_actions : x->d_actions;
   a.elog = x->elog ? x->elog + (size_t)x->elog_n * 2 * (size_t)((x->n + 63) >> 6) : nullptr;
-  a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j; a.g0 = ticks_before(x, j);
-  a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_ticks = (int)(ticks_before(x, j + 1) - a.g0);
+  a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j;
+  for (int p = 0; p < DQL_MAX_PERIODS; ++p) { a.g0[p] = ticks_before(x, j + p); a.n_ticks[p] = (int)(ticks_before(x, j + p + 1) - a.g0[p]); }
+  a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_periods = n_periods;
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
   return a;
 }
-template <typename T, int BLOCK, bool LONE> static void launch_step_t(dql_ctx* x, int mode, double eps) {
-  const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK);
+template <typename T, int BLOCK, bool LONE> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
+  const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK, n_periods);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL((k_step<T, BLOCK, LONE>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
-template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps) {
+template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps, int np) {
   // measured on MI355X (profiles/r1_sweep_blocks.jsonl): single-wave workgroups up to 8192 envs, 256 threads above
   int block = x->block;
   if (block == 0) block = (x->n <= 8192) ? 64 : 256;
   const bool lone = x->n <= DQL_LONE_MAX;
-  if (block == 64) { if (lone) launch_step_t<T, 64, true>(x, mode, eps); else launch_step_t<T, 64, false>(x, mode, eps); }
-  else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps);
-  else { if (lone) launch_step_t<T, 256, true>(x, mode, eps); else launch_step_t<T, 256, false>(x, mode, eps); }
+  if (block == 64) { if (lone) launch_step_t<T, 64, true>(x, mode, eps, np); else launch_step_t<T, 64, false>(x, mode, eps, np); }
+  else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps, np);
+  else { if (lone) launch_step_t<T, 256, true>(x, mode, eps, np); else launch_step_t<T, 256, false>(x, mode, eps, np); }
 }
-// ONE kernel per agent period
-static int launch_period(dql_ctx* x, int mode, double eps) {
-  if (x->elog && x->elog_n >= x->elog_cap) return fail(DQL_ESTATE, "episode log full: read it with dql_episode_log_read before stepping on");
+// ONE kernel per launch of n_periods (1 .. periods_per_launch) agent periods
+static int launch_period(dql_ctx* x, int mode, double eps, int n_periods = 1) {
+  if (x->elog && x->elog_n + n_periods > x->elog_cap) return fail(DQL_ESTATE, "episode log full: read it with dql_episode_log_read before stepping on");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (x->kernel_timer) {
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, x->stream));
   }
-  if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps); else launch_step_b<double>(x, mode, eps);
+  if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps, n_periods); else launch_step_b<double>(x, mode, eps, n_periods);
   if (x->kernel_timer) { HIP_TRY(hipEventRecord(e1, x->stream)); x->kev.push_back(e0); x->kev.push_back(e1); }
   HIP_TRY(hipGetLastError());
-  if (x->elog) x->elog_n += 1;
+  if (x->elog) x->elog_n += n_periods;
   x->pending = (mode == MODE_TRAIN);  // this launch's accumulators wait for the next launch's writer blocks (or a flush)
-  if (x->windowed && mode == MODE_TRAIN) x->window_launches += 1;
-  x->step_index += 1;
+  x->pending_periods = n_periods;
+  if (x->windowed && mode == MODE_TRAIN) x->window_launches += n_periods;  // counted in agent periods
+  x->step_index += n_periods;
+  x->launch_index += 1;
   x->timer_launches += 1;
   return DQL_OK;
 }
 // fold the last launch's accumulators into the master tables now
 static int flush_pending(dql_ctx* x) {
   if (!x->pending) return DQL_OK;
-  FlushArgs f{x->qa, x->qb, x->count, x->acc[(x->step_index + 1) & 1], x->window, make_foldk(x), x->windowed ? 1 : 0};
+  FlushArgs f{x->qa, x->qb, x->count, x->acc[(x->launch_index + 1) & 1], x->window, make_foldk(x, x->pending_periods), x->windowed ? 1 : 0};
   hipLaunchKernelGGL(k_flush, dim3((DQL_N_CELLS + 255) / 256), dim3(256), 0, x->stream, f);
   HIP_TRY(hipGetLastError());
   x->pending = false;
@@ -829,14 +855,22 @@ int dql_train_steps(dql_ctx* x, int32_t n_steps, double eps) {
   CHECK_CTX(x);
   if (n_steps < 0) return fail(DQL_EINVAL, "n_steps must be >= 0");
   HIP_TRY(hipSetDevice(x->device));
-  for (int i = 0; i < n_steps; ++i) { int rc = launch_period(x, MODE_TRAIN, eps); if (rc) return rc; }
+  for (int i = 0; i < n_steps;) {
+    const int np = n_steps - i < x->periods_per_launch ? n_steps - i : x->periods_per_launch;
+    int rc = launch_period(x, MODE_TRAIN, eps, np); if (rc) return rc;
+    i += np;
+  }
   return DQL_OK;
 }
 int dql_eval_steps(dql_ctx* x, int32_t n_steps) {
   CHECK_CTX(x);
   if (n_steps < 0) return fail(DQL_EINVAL, "n_steps must be >= 0");
   HIP_TRY(hipSetDevice(x->device));
-  for (int i = 0; i < n_steps; ++i) { int rc = launch_period(x, MODE_EVAL, 0.0); if (rc) return rc; }
+  for (int i = 0; i < n_steps;) {
+    const int np = n_steps - i < x->periods_per_launch ? n_steps - i : x->periods_per_launch;
+    int rc = launch_period(x, MODE_EVAL, 0.0, np); if (rc) return rc;
+    i += np;
+  }
   return DQL_OK;
 }
 
@@ -1143,6 +1177,11 @@ int dql_sync_time_ms(dql_ctx* x, double* avg_ms, int64_t* syncs) {
 int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");
+  if (!strcmp(name, "periods_per_launch")) {
+    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..4");
+    x->periods_per_launch = value;
+    return DQL_OK;
+  }
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(DQL_EINVAL, "block must be 0, 64, 128 or 256"); x->block = value; return DQL_OK; }
   return fail(DQL_EINVAL, std::string("unknown option ") + name);
 }

@@ -249,7 +249,12 @@ int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
 int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
 /* holds the context's stream for this long (a one-wave timer kernel): phase offset between contexts that share a GPU */
 int dql_delay(dql_ctx* ctx, double microseconds);
-/* tuning knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup) */
+/* knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup);
+ * "periods_per_launch" P in 1..4 (default 1): dql_train_steps / dql_eval_steps run P agent periods per kernel launch — every env
+ * stays in registers between them, so the state round trip through HBM and the launch boundary are paid once per P periods.
+ * Table timing in units of launches is unchanged (a launch acts on every accumulator up to the launch before the previous one,
+ * all P periods of a launch act on the same tables and add to the same accumulators; a per-step fold takes min(visits, P)
+ * learning-rate steps per launch); P = 1 is the period-by-period schedule.  n_steps need not be a multiple of P. */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 
 /* ---- episode log (Trainer promotion rule, pkg/trainer.py:218-232) ----

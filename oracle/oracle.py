@@ -75,6 +75,8 @@ class Oracle:
         self.stats = np.zeros(12, dtype=np.int64)
         self.alpha_tab = cfg.alpha_table() if alpha_tab is None else _f64(alpha_tab)
         self.step_index = 0
+        self.periods_per_launch = 1   # the product's option of the same name: P periods per launch act on the same tables
+        self.pending_periods = 1
         self.windowed = False
         self.n_threads = int(n_threads)
         self._elog = None
@@ -154,7 +156,7 @@ class Oracle:
         if self.pending is not None:
             if self.windowed:
                 self.window += self.pending
-            self._contract(self._qa, self._qb, self._count, self.pending)
+            self._contract(self._qa, self._qb, self._count, self.pending, self.pending_periods)
             self.pending = None
 
     def flush(self):
@@ -166,7 +168,25 @@ class Oracle:
         self.flush()
         self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
 
-    def _period(self, mode, eps=0.0, actions=None):
+    def set_option(self, name, value):
+        if name == "periods_per_launch":
+            self.periods_per_launch = int(value)
+
+    def _period(self, mode, eps=0.0, actions=None, n_periods=1):
+        """one LAUNCH of n_periods agent periods: same acting tables, one set of accumulators"""
+        for _ in range(n_periods):
+            self._one_period(mode, eps, actions)
+        # what the writer workgroups of this launch do meanwhile: fold the previous launch, publish the acting tables of the next
+        self._fold_pending()
+        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
+        if mode == 0:
+            self.pending = self.accum.copy()
+            self.pending_periods = n_periods
+            if self.windowed:
+                self.window_launches += n_periods
+        self.accum[:] = 0
+
+    def _one_period(self, mode, eps=0.0, actions=None):
         j = self.step_index
         g0 = self.cfg.ticks_before(j)
         n_ticks = self.cfg.ticks_before(j + 1) - g0
@@ -186,14 +206,6 @@ class Oracle:
                 pad[:] = 0; pad[:self.n] = m
                 row.append(np.packbits(pad.reshape(nw, 64), axis=1, bitorder="little").view(np.uint64).reshape(nw).copy())
             self._elog.append(row)
-        # what the writer workgroups of this launch do meanwhile: fold launch j-1, publish the acting tables of launch j+1
-        self._fold_pending()
-        self.qa_act[:] = self._qa; self.qb_act[:] = self._qb
-        if mode == 0:
-            self.pending = self.accum.copy()
-            if self.windowed:
-                self.window_launches += 1
-        self.accum[:] = 0
 
     # ---- windowed (multi-rank) semantics: same interface as the product Engine ----
     def set_windowed(self, on: bool):
@@ -230,12 +242,18 @@ class Oracle:
         return np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])
 
     def train_steps(self, n_steps: int, eps: float):
-        for _ in range(n_steps):
-            self._period(0, eps)
+        left = int(n_steps)
+        while left > 0:
+            k = min(left, self.periods_per_launch)
+            self._period(0, eps, n_periods=k)
+            left -= k
 
     def eval_steps(self, n_steps: int):
-        for _ in range(n_steps):
-            self._period(1)
+        left = int(n_steps)
+        while left > 0:
+            k = min(left, self.periods_per_launch)
+            self._period(1, n_periods=k)
+            left -= k
 
     def step(self, actions):
         self._period(2, actions=actions)

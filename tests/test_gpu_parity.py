@@ -329,3 +329,36 @@ def test_double_q_learning_updates_both_tables_in_paper_mode(mods):
         assert acc.shape == (4 * 2835,) and np.array_equal(acc, orc.get_accum()) and acc[2 * 2835:].any()
         eng.apply_accum(); orc.flush(); orc.apply_accum()
         _compare(eng, orc, exact=True, what="windowed double Q")
+
+
+@pytest.mark.parametrize("P,n,block,kw", [(2, 4096, 0, {}), (3, 300, 64, dict(quirks=Q_PAPER, fold_per_step=1)), (4, 9000, 256, dict(t_max=3.0)),
+                                          (2, 20000, 0, dict(two_axis=1, quirks=Q_PAPER)), (4, 70, 0, dict(dtype=F64, t_max=2.0, fold_per_step=1))])
+def test_periods_per_launch_bit_exact(mods, P, n, block, kw):
+    """Option "periods_per_launch": P agent periods per kernel launch with the env in registers in between (one state round trip,
+    one launch boundary, one table publication per P periods).  Same per-period arithmetic, RNG counters and tick schedule; the
+    launch's tables act for all P periods and its accumulators collect all of them — the oracle groups its periods the same way.
+    Step counts that are not multiples of P, resets inside a launch (short episodes), the episode log's P rows per launch."""
+    Engine, Oracle = mods
+    kw = dict(kw); dtype = kw.pop("dtype", F32)
+    eng = Engine(DqlConfig(dtype=dtype, **kw), n, seed=11); orc = Oracle(DqlConfig(dtype=dtype, **kw), n, seed=11)
+    eng.set_option("periods_per_launch", P); orc.set_option("periods_per_launch", P)
+    eng.set_option("block", block)
+    cap = 64
+    eng.episode_log_enable(cap); orc.episode_log_enable(cap)
+    for steps, eps in ((P * 5 + 1, 1.0), (7, 0.3), (P * 9 + (P - 1), 0.0)):
+        eng.train_steps(steps, eps); orc.train_steps(steps, eps)
+        _compare(eng, orc, exact=True, what=f"P={P} steps={steps}")
+        d1, g1 = eng.episode_log_read(); d2, g2 = orc.episode_log_read()
+        assert d1.shape[0] == steps and np.array_equal(d1, d2) and np.array_equal(g1, g2)
+    se, so = eng.stats(), orc.stats_dict()
+    assert se["decisions"] == so["decisions"] and se["episodes"] == so["episodes"] and se["reward_sum"] == so["reward_sum"]
+    assert se["agent_steps"] == sum((P * 5 + 1, 7, P * 9 + (P - 1)))
+    eng.eval_steps(2 * P + 1); orc.eval_steps(2 * P + 1)
+    _compare(eng, orc, exact=True, what="eval")
+    # windowed exchange on top: the window counts agent periods, the fold takes min(visits, periods) learning-rate steps
+    eng.set_windowed(True); orc.set_windowed(True)
+    eng.train_steps(2 * P, 0.5); orc.train_steps(2 * P, 0.5)
+    eng.flush(); orc.flush(); eng.apply_accum(); orc.apply_accum()
+    _compare(eng, orc, exact=True, what="windowed")
+    with pytest.raises(ValueError):
+        eng.set_option("periods_per_launch", 5)
