@@ -66,8 +66,9 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
     """Second half of BASELINE.json's metric: wall-clock to curriculum stage 4.  The Trainer's loop (reference promotion rule:
     100-episode deque > 0.96 or the level's episode budget runs out) on the same envs-per-GPU, sharded over the ranks of this
     job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).  Same table schedule
-    (sync_period 2, the regime in which the run does not depend on the number of ranks) at any N, one GPU included, so the
+    (same sync period and periods per launch) at any N, one GPU included, so the
     figures of a scaling sweep are the same run on more hardware.  Never fails the bench."""
+    # (sync_period CURRICULUM_SYNC: the windowed schedule also on one GPU, so that N = 1 and N = 8 run the same algorithm)
     import tempfile
     try:
         from dql_multirotor_landing_amd.config import Q_PAPER
@@ -82,11 +83,11 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
 
         # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
         # generations of all of them, or a level ends before most envs have finished an episode (Trainer default)
-        budget = max(args.curriculum_budget, 64 * args.envs * world)
+        budget = max(args.curriculum_budget, 384 * args.envs * world)
         runs = []
         for seed in (42, 1, 2):  # tabular RL is seed-noisy: three full curricula, each reported
             with tempfile.TemporaryDirectory() as d:
-                tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=2,
+                tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=CURRICULUM_SYNC,
                              max_num_episodes=budget, checkpoint_every=10**9, comm=comm, seed=seed, **CURRICULUM_KW)
                 t0 = time.perf_counter()
                 hist = tr.curriculum_training()
@@ -101,8 +102,8 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
         if rank != 0:
             return None
         mean = lambda k: sum(r[k] for r in runs) / len(runs)
-        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper (Double Q-learning), one learning-rate step per launch (Trainer default)",
-                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": 2, "trainer_kw": CURRICULUM_KW,
+        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper-mode MDP, reference update rule (quirks 0x60), one learning-rate step per agent period (Trainer default)",
+                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": CURRICULUM_SYNC, "trainer_kw": CURRICULUM_KW,
                 "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
@@ -113,7 +114,12 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
         return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]} if rank == 0 else None
 
 
-CURRICULUM_KW: dict = {}  # Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line)
+# Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
+# (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
+# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl); one judged env
+# = the deque sees one env's episodes in order, as in the reference; 4 agent periods per launch, table exchange every 4
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 1, "periods_per_launch": 4}
+CURRICULUM_SYNC = 4
 
 
 def spawn_ranks(args) -> int:
@@ -175,6 +181,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1.0)
     ap.add_argument("--sync-period", type=int, default=32, help="agent periods between table exchanges of the headline run (N > 1); sync_period 2 is reported next to it")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--periods-per-launch", type=int, default=4, help="agent periods per kernel launch (engine option; 1 = one launch per period)")
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
@@ -218,6 +225,10 @@ def main():
                     noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
+    eng.set_option("periods_per_launch", args.periods_per_launch)
+    if args.steps % args.periods_per_launch or args.sync_period % args.periods_per_launch:
+        print("bench.py: --steps and --sync-period must be multiples of --periods-per-launch", file=sys.stderr)
+        sys.exit(2)
     reducer = RcclWindowReducer(eng, comm) if world > 1 else None
 
     def barrier():
@@ -267,14 +278,15 @@ def main():
     # rocprofv3's kernel summary of the same command reports.  Event PAIRS around single
     # launches (second figure) add the event records and an idle boundary per launch; with several ranks the timed region also
     # holds the exchange kernels, so there the pairs are the per-launch figure.
+    P = args.periods_per_launch
     s1 = eng.stats()
     eng.kernel_timer(True)
-    eng.train_steps(min(200, max(20, args.steps // 10)), args.eps)
+    eng.train_steps(P * min(200, max(20, args.steps // (10 * P))), args.eps)
     k_pairs_ms, k_n = eng.kernel_time_ms()
     eng.kernel_timer(False)
     s2 = eng.stats()
-    dec_per_launch = (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])
-    k_ms = dev_ms / args.steps if world == 1 else k_pairs_ms
+    dec_per_launch = P * (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])  # one launch = P agent periods
+    k_ms = dev_ms / (args.steps // P) if world == 1 else k_pairs_ms
 
     curriculum = None
     if not args.no_curriculum and not args.two_axis:
@@ -298,13 +310,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
-                                   f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per agent period (env step + table fold in writer workgroups), int64 LDS/global accumulators",
+                                   f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per {args.periods_per_launch} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
+                       "periods_per_launch": args.periods_per_launch,
                        "parallelism": f"env-shard x{world}" + (", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)" if world > 1 else ""), "block": args.block,
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": args.steps if world == 1 else k_n,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": args.steps // P if world == 1 else k_n, "agent_periods_per_launch": P,
                          "kernel_avg_ms_event_pairs": k_pairs_ms,
                          "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
@@ -319,10 +332,11 @@ def main():
         if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
             # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
             big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis), args.large_envs, seed=42)
-            big.train_steps(20, args.eps); big.sync()
-            b0 = big.stats(); big.timer_start(); big.train_steps(150, args.eps); b_ms = big.timer_stop(); b1 = big.stats()
+            big.set_option("periods_per_launch", P)
+            big.train_steps(5 * P, args.eps); big.sync()
+            b0 = big.stats(); big.timer_start(); big.train_steps(40 * P, args.eps); b_ms = big.timer_stop(); b1 = big.stats()
             b_dec = b1["decisions"] - b0["decisions"]
-            out["large_batch"] = {"envs": args.large_envs, "value": b_dec / (b_ms * 1e-3), "unit": "env-steps/s", "ms_per_step": b_ms / 150,
+            out["large_batch"] = {"envs": args.large_envs, "value": b_dec / (b_ms * 1e-3), "unit": "env-steps/s", "ms_per_step": b_ms / (40 * P), "periods_per_launch": P,
                                   "hbm_frac_algorithmic": algo_b * b_dec / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             big.close()
         if curriculum is not None:
@@ -354,7 +368,7 @@ def valu_roofline(args, k_ms):
     if not ref:
         return None
     ref_envs = args.envs if str(args.envs) in pm else (1048576 if args.envs > 262144 else 4096)
-    valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64)
+    valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64) * (args.periods_per_launch / ref.get("periods_per_launch", 1))  # per launch
     waves = (args.envs + 63) // 64
     out = {"valu_instr_per_env_wave": valu_per_wave, "simds": 1024, "source": f"profiles/{pf.name}"}
     # two prices per instruction: what tools/micro/valu_rate.hip measures on this chip, and MI355X_MICROARCH.md's table

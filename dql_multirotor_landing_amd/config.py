@@ -33,8 +33,12 @@ Q_SHAPING_SURVIVES_RESET = 1 << 2
 Q_FROZEN_ACC_REFERENCE = 1 << 3
 Q_BOOTSTRAP_ON_POS_CHANGE = 1 << 4
 Q_UPDATE_TABLE_A_ONLY = 1 << 5
-Q_REFERENCE = 0x3F
-Q_PAPER = 0
+Q_GOAL_COUNT_KEPT = 1 << 6
+Q_REFERENCE = 0x7F
+# mode="paper": the reference's code with its reward / observation / update quirks repaired, and its success criterion kept: f_ag
+# goal-bin steps at the working level in total (pkg/mdp.py:402-425) — what its trainer promotes on (B17)
+Q_PAPER = Q_GOAL_COUNT_KEPT
+Q_NONE = 0  # additionally: the success counter restarts whenever the goal bins are left
 
 # CheckResult codes in declaration order of pkg/mdp.py:68-77
 CHECK_NAMES = (
@@ -192,7 +196,10 @@ class DqlConfig:
 
     def alpha_table(self, n: int = 1536) -> np.ndarray:
         """alpha(count) exactly as Trainer.alpha computes it (pkg/trainer.py:88-110): count 0 -> alpha_min,
-        else max(float_power(1/count, omega), alpha_min).  The table must reach the alpha_min plateau."""
+        else max(float_power(1/count, omega), alpha_min).  The table must reach the alpha_min plateau (1 536 entries do for the
+        reference's alpha_min; smaller floors get as many as they need)."""
+        if 0 < self.alpha_min < 1 and self.alpha_omega > 0:
+            n = max(n, min(1 << 22, int(self.alpha_min ** (-1.0 / self.alpha_omega)) + 8))
         tab = np.empty(n, dtype=np.float64)
         tab[0] = self.alpha_min
         for cnt in range(1, n):

@@ -337,7 +337,7 @@ DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int cod
     } else {
       cur_check = 0;
     }
-  } else if (!(m.quirks & DQL_Q_STICKY_CHECK)) {
+  } else if (!(m.quirks & DQL_Q_GOAL_COUNT_KEPT)) {
     cur_check = 0;
   }
   return code;

@@ -29,9 +29,14 @@ schedule (exchange = identity) as 8 GPUs with `sync_period=S`, bit for bit for S
 Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chunk_steps, checkpoint_every, quiet,
 promotion_rule, judge_envs, sync_period, max_steps_per_level, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
 exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
-generation, so `eps_episode_scale = s` reads the schedule at episodes / s), checkpoint_env_state.
-`max_num_episodes=None` (default) is the reference's 50 000 per level, but at least 64 per env: the reference's figure is
-sized for one env, and a level has to see a few generations of every env.
+generation, so `eps_episode_scale = s` reads the schedule at episodes / s), checkpoint_env_state, periods_per_launch (agent periods
+per kernel launch, engine option of the same name: the tables the envs act on are refreshed once per launch; 1 = every period).
+`max_num_episodes=None` (default) is the reference's 50 000 per level, but at least 384 per env: the reference's figure is
+sized for one env, and a level has to last until the judged envs have flown a few hundred episodes each.
+`judge_envs` (default 1): whose episodes feed the promotion deque.  1 is the reference's own situation — ONE env's episodes in the
+order it flies them; every further judged env adds windows per unit of training, so levels hand over earlier and less trained
+(measured, profiles/r2_curriculum_reference_counter_sweep*.jsonl: 4 096 judged envs promote after 3-60 episodes per env and land
+70 % of the final policy's approaches, 1 judged env after 100-400 episodes per env and lands 90 %).
 `fold_per_step` (default 1): how a launch's m visits of a table cell move its value.  0: as m sequential visits (the
 contraction over alpha(c) .. alpha(c+m-1)); 1: one learning-rate step towards the launch's mean target.  For one env both
 are the reference's rule (m <= 1).  With thousands of envs a cell collects hundreds of visits per launch and the
@@ -74,7 +79,7 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
-               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state")
+               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch")
 
 
 class Trainer:
@@ -86,8 +91,8 @@ class Trainer:
                  n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
-                 judge_envs: Optional[int] = 4096, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
-                 comm=None, reducer_factory=None) -> None:
+                 judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
+                 periods_per_launch: int = 1, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -112,8 +117,9 @@ class Trainer:
         self._successes = deque([], maxlen=successive_successful_episodes)
         # build-specific
         self._n_envs, self._device, self._dtype, self._mode = int(n_envs), device, dtype, mode
-        # the reference's 50 000 episodes per level are sized for ONE env; N envs need a few generations each
-        self._max_num_episodes = max(50000, 64 * self._n_envs) if max_num_episodes is None else int(max_num_episodes)
+        # the reference's 50 000 episodes per level are sized for ONE env; with N envs the level has to last until the judged env(s)
+        # have flown a few hundred episodes (the deque wants 100 of them), i.e. a few hundred episodes PER env
+        self._max_num_episodes = max(50000, 384 * self._n_envs) if max_num_episodes is None else int(max_num_episodes)
         self._chunk_steps, self._checkpoint_every, self._quiet = int(chunk_steps), int(checkpoint_every), quiet
         self._max_steps_per_level = max_steps_per_level
         self._fold_per_step, self._eps_floor = int(fold_per_step), float(eps_floor)
@@ -124,6 +130,9 @@ class Trainer:
         self._judge_envs_arg = judge_envs
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
         self._checkpoint_env_state = bool(checkpoint_env_state)
+        self._periods_per_launch = int(periods_per_launch)
+        if not 1 <= self._periods_per_launch <= 4 or self._chunk_steps % self._periods_per_launch:
+            raise ValueError("periods_per_launch must be in 1..4 and divide chunk_steps")
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
         self._reducer_factory = reducer_factory
         self._rank = self._comm.rank if self._comm else 0
@@ -246,10 +255,12 @@ class Trainer:
     def _make_engine(self, cfg):
         sync = self._sync_period if self._sync_period is not None else (2 if self._world > 1 else None)
         if self._world > 1 or self._reducer_factory is not None or sync is not None:
-            if self._chunk_steps % sync:
-                raise ValueError("chunk_steps must be a multiple of sync_period (checkpoints and promotions happen on synchronised tables)")
+            if self._chunk_steps % sync or sync % self._periods_per_launch:
+                raise ValueError("chunk_steps must be a multiple of sync_period (checkpoints and promotions happen on synchronised tables) and sync_period of periods_per_launch")
             lo, hi = shard_range(self._n_envs, self._rank, self._world)
             eng = Engine(cfg, hi - lo, seed=self._seed, device=self._device, env_id_offset=lo)
+            if self._periods_per_launch != 1:
+                eng.set_option("periods_per_launch", self._periods_per_launch)
             if self._reducer_factory is not None:
                 make = self._reducer_factory
             elif self._world > 1:
@@ -258,6 +269,8 @@ class Trainer:
                 make = LocalWindowReducer  # one rank on the windowed schedule: what N ranks with this sync period do
             return eng, ShardedRunner(eng, make(eng), sync)
         eng = Engine(cfg, self._n_envs, seed=self._seed, device=self._device)
+        if self._periods_per_launch != 1:
+            eng.set_option("periods_per_launch", self._periods_per_launch)
         return eng, ShardedRunner(eng, None)
 
     def _chunk_counters(self, s, s_prev):

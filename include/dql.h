@@ -47,10 +47,11 @@ enum {
   DQL_N_CHECK_CODES = 9
 };
 
-/* Quirk switches.  mode="reference" = all set; mode="paper" = 0. */
+/* Quirk switches.  mode="reference" = all set; mode="paper" = DQL_Q_GOAL_COUNT_KEPT only. */
 enum {
   DQL_Q_FAIL_TERM_EVERY_STEP = 1 << 0,  /* B7  pkg/mdp.py:528-536 */
-  DQL_Q_STICKY_CHECK = 1 << 1,          /* B8  pkg/mdp.py:363-425 */
+  DQL_Q_STICKY_CHECK = 1 << 1,          /* B8  pkg/mdp.py:363-425: _check_result is only ever set inside an episode, so after the first
+                                         * NON_TERMINAL_SUCCESS every later step keeps the success code (and its reward term) */
   DQL_Q_SHAPING_SURVIVES_RESET = 1 << 2,/* B9  pkg/mdp.py:196-197,469-474 */
   DQL_Q_FROZEN_ACC_REFERENCE = 1 << 3,  /* B19 pkg/observation_utils.py:137-150: last_velocity never updated */
   DQL_Q_BOOTSTRAP_ON_POS_CHANGE = 1 << 4,/* B3  pkg/double_q_learning.py:139-145 */
@@ -58,7 +59,13 @@ enum {
                                          * it values its own greedy action.  Cleared (mode="paper"): Double Q-learning as the paper
                                          * has it: a fair coin picks the table to update, the OTHER table values the picked
                                          * table's greedy action at s'; Q_table_b learns too. */
-  DQL_Q_REFERENCE = 0x3f
+  DQL_Q_GOAL_COUNT_KEPT = 1 << 6,       /* second half of B8, pkg/mdp.py:402-425: _curriculum_check counts the steps spent in the goal bins at
+                                         * the working level and is reset only by a goal-bin step at another level — leaving the bins keeps
+                                         * it, so "Goal state reached" needs f_ag such steps in TOTAL, not in a row.  This is the success
+                                         * criterion the reference's trainer promotes on (B17), kept in paper mode.  Cleared: the counter
+                                         * restarts whenever the goal bins are left (one second WITHOUT interruption inside the innermost
+                                         * bins: stricter than the code and than the paper's "in that curriculum step's discrete states") */
+  DQL_Q_REFERENCE = 0x7f
 };
 
 enum { DQL_F32 = 0, DQL_F64 = 1 };

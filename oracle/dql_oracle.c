@@ -362,8 +362,8 @@ static int mdp_check(const mdpc_t* m, int* step_count, int* cur_check, int code,
     } else {
       *cur_check = 0;
     }
-  } else if (!(m->quirks & DQL_Q_STICKY_CHECK)) {
-    *cur_check = 0; /* paper mode: leaving the goal region loses the progress */
+  } else if (!(m->quirks & DQL_Q_GOAL_COUNT_KEPT)) {
+    *cur_check = 0; /* strict variant: leaving the goal bins loses the progress (the reference keeps it, pkg/mdp.py:402-425) */
   }
   return code;
 }

@@ -299,7 +299,7 @@ def agent_predict(qa, qb, idx):
     return out
 
 
-def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks=0x3F, coin=None, done=None):
+def agent_update(qa, qb, count, sa, ns, alpha, gamma, reward, quirks=0x7F, coin=None, done=None):
     sa = np.ascontiguousarray(sa, dtype=np.int32); ns = np.ascontiguousarray(ns, dtype=np.int32)
     alpha = _f64(alpha); reward = _f64(reward)
     u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)

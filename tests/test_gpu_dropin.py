@@ -193,7 +193,7 @@ def test_trainer_full_curriculum_hip_equals_oracle_engine(tmp_path, monkeypatch)
         def all_reduce(self): self.eng.flush()
 
     kw = dict(curriculum_steps=5, n_envs=320, chunk_steps=16, sync_period=4, checkpoint_every=10**9, max_num_episodes=400, t_max=4,
-              successive_successful_episodes=20, success_rate=0.2, mode="paper", reducer_factory=LocalReducer)
+              successive_successful_episodes=20, success_rate=0.2, mode="paper", reducer_factory=LocalReducer, judge_envs=320)
     hip = T.Trainer(save_path=tmp_path / "hip", **kw)
     h_hip = _strip(hip.curriculum_training())
     monkeypatch.setattr(T, "Engine", _oracle_engine_class())

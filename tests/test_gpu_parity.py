@@ -312,7 +312,7 @@ def test_double_q_learning_updates_both_tables_in_paper_mode(mods):
     env_agent_period); with it, Q_table_b never changes.  Both tables and the shared counter bit-exact, windowed too."""
     Engine, Oracle = mods
     n = 640
-    for quirks, expect_b in ((Q_PAPER, True), (0x3F, False)):
+    for quirks, expect_b in ((Q_PAPER, True), (0x7F, False)):
         eng = Engine(DqlConfig(dtype=F32, quirks=quirks), n, seed=5)
         orc = Oracle(DqlConfig(dtype=F32, quirks=quirks), n, seed=5, n_threads=8)
         eng.train_steps(150, 0.5); orc.train_steps(150, 0.5)

@@ -225,13 +225,13 @@ def test_trainer_ordered_promotion_and_budget(tmp_path, monkeypatch):
             return {"episodes": self.tot[0], "by_code": by, "decisions": self.tot[2], "reward_sum": 0.0}
 
     monkeypatch.setattr(T, "Engine", FakeEngine)
-    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=50, chunk_steps=4, checkpoint_every=10**9, max_num_episodes=1000)
+    tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run", n_envs=50, chunk_steps=4, checkpoint_every=10**9, max_num_episodes=1000, judge_envs=50)
     hist = tr.curriculum_training()
     # level 0: completions F S*49 F S*49 F ...: after 99 episodes the deque holds 97 successes (failures at 0 and 50): 97 / 100 > 0.96
     assert hist[0]["promoted"] and hist[0]["promoted_at"] == {"judged_episode": 99} and hist[0]["agent_periods"] == 4
     assert not hist[1]["promoted"] and hist[1]["exhausted"] and hist[1]["episodes"] == 1000  # budget ran out: next level anyway
     assert hist[2]["promoted"] and [h["level"] for h in hist] == [0, 1, 2]
     tr = T.Trainer(curriculum_steps=3, save_path=tmp_path / "run2", n_envs=50, chunk_steps=4, checkpoint_every=10**9, max_steps_per_level=8,
-                   initial_curriculum_step=1)
+                   initial_curriculum_step=1, judge_envs=50)
     hist = tr.curriculum_training()
     assert [h["level"] for h in hist] == [1] and not hist[0]["promoted"] and not hist[0]["exhausted"]

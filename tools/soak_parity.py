@@ -18,7 +18,7 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for k in range(n_cfg):
-    kw = dict(dtype=int(rng.choice([F32, F32, F64])), working_curriculum_step=int(rng.integers(0, 5)), quirks=int(rng.choice([0x3F, 0x00, 0x37, 0x20, int(rng.integers(0, 64))])),
+    kw = dict(dtype=int(rng.choice([F32, F32, F64])), working_curriculum_step=int(rng.integers(0, 5)), quirks=int(rng.choice([0x7F, 0x00, 0x40, 0x77, 0x60, int(rng.integers(0, 128))])),
               two_axis=int(rng.random() < 0.3), fold_per_step=int(rng.random() < 0.2), t_max=float(rng.choice([20.0, 4.0, 2.0])))
     if rng.random() < 0.3: kw["trajectory"] = TRAJ_EIGHT
     if rng.random() < 0.3: kw.update(per_env_platform=1)
