@@ -116,9 +116,11 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
 
 # Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
 # (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
-# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl); one judged env
-# = the deque sees one env's episodes in order, as in the reference; 4 agent periods per launch, table exchange every 4
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 1, "periods_per_launch": 4}
+# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl); 4 judged envs:
+# the deque sees the episodes of 4 envs (1 = the reference's own situation is the Trainer's default: same policy quality, a level
+# that sits at 93-95 % online success then needs ~2x the episodes until a 97 / 100 window comes by); 4 agent periods per launch,
+# table exchange every 4
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 4}
 CURRICULUM_SYNC = 4
 
 
@@ -295,14 +297,13 @@ def main():
     if rank == 0:
         value = decisions / wall
         traffic, traffic_note = None, "no committed PMC pass for this envs/block configuration"
-        for name in ("r2_traffic.json", "r1_traffic.json"):
-            tf = ROOT / "profiles" / name
-            if tf.exists():
-                t = json.loads(tf.read_text())["configs"].get(str(args.envs))
-                if t:
-                    traffic = t["hbm_bytes_per_env"] * dec_per_launch
-                    traffic_note = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction) x env-steps per launch of this run"
-                    break
+        tf = ROOT / "profiles" / "r2_traffic.json"
+        if tf.exists():
+            t = json.loads(tf.read_text())["configs"].get(f"{args.envs}_p{P}")
+            if t:
+                traffic = t["hbm_bytes_per_env_step"] * dec_per_launch
+                traffic_note = ("profiles/r2_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction), HBM bytes "
+                                "per env-step of the same envs / periods-per-launch configuration x env-steps per launch of this run")
         algo_b = ALGO_BYTES_PER_ENV_STEP_2AXIS if args.two_axis else ALGO_BYTES_PER_ENV_STEP
         ach = algo_b * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
@@ -360,21 +361,23 @@ def valu_roofline(args, k_ms):
     the instruction count per env wave from the committed PMC pass."""
     if args.two_axis or args.dtype != "f32":
         return None
-    pf = next((ROOT / "profiles" / n for n in ("r2_pmc_sq_summary.json", "r1_pmc_sq_summary.json") if (ROOT / "profiles" / n).exists()), None)
-    if pf is None:
+    pf = ROOT / "profiles" / "r2_pmc_sq_summary.json"
+    if not pf.exists():
         return None
     pm = json.loads(pf.read_text())
-    ref = pm.get(str(args.envs)) or (pm.get("1048576") if args.envs > 262144 else pm.get("4096"))
+    P = args.periods_per_launch
+    ref = pm.get(f"{args.envs}_p{P}") or pm.get(f"{1048576 if args.envs > 262144 else 4096}_p{P}")
     if not ref:
         return None
-    ref_envs = args.envs if str(args.envs) in pm else (1048576 if args.envs > 262144 else 4096)
-    valu_per_wave = ref["SQ_INSTS_VALU"] / (ref_envs / 64) * (args.periods_per_launch / ref.get("periods_per_launch", 1))  # per launch
+    valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * P  # per launch
     waves = (args.envs + 63) // 64
-    out = {"valu_instr_per_env_wave": valu_per_wave, "simds": 1024, "source": f"profiles/{pf.name}"}
-    # two prices per instruction: what tools/micro/valu_rate.hip measures on this chip, and MI355X_MICROARCH.md's table
-    # (v_fma_f32: 2 cycles with >= 2 waves per SIMD, 4 for a lone wave) at 2.4 GHz
+    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "source": f"profiles/{pf.name}"}
+    # two prices per wave64 f32 VALU instruction per SIMD: what tools/micro/valu_rate.hip measures on this chip with the placement
+    # verified (profiles/r2_valu_rate.jsonl: 4.64 cycles for a lone wave with instruction-level parallelism, 4.06-4.3 with 2-8 waves,
+    # at 2.3-2.4 GHz), and MI355X_MICROARCH.md's table row (2 cycles with >= 2 waves per SIMD, 4 for a lone wave; reached on this
+    # chip only by packed v_pk_fma_f32, which does two FMAs in those 4 cycles)
     lone = waves <= 1024
-    for tag, ns in (("measured_micro", 1.9), ("guide_table", (4 if lone else 2) / 2.4)):
+    for tag, ns in (("measured_micro", 1.94 if lone else 1.74), ("guide_table", (4 if lone else 2) / 2.4)):
         floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)
         out[tag] = {"ns_per_wave64_valu_instr_per_simd": ns, "floor_ms_per_launch": floor_s * 1e3, "frac": floor_s * 1e3 / k_ms if k_ms > 0 else None}
     out["note"] = "informational: the fused step is bound by VALU issue (one wave's instruction stream at small batches, all SIMDs busy at large ones), not by HBM"

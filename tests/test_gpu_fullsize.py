@@ -98,3 +98,41 @@ def test_shard_invariance_1m_envs(Engine):
     np.testing.assert_array_equal(reals[:, lo:lo + m], o_r)
     for e in parts + [whole, ref]:
         e.close()
+
+
+def test_config5_flags_at_131072_envs(Engine):
+    """BASELINE configs[4] per-GPU share: 131 072 envs with per-env platform amplitude / speed, observation noise and the Kalman
+    filter, 4 agent periods per launch: run-to-run determinism, conservation, and a 192-env slice of the run == the oracle on the
+    same global env ids reading the same tables (no learning in the slice comparison: greedy evaluation periods)."""
+    from oracle.oracle import Oracle
+    kw = dict(dtype=F32, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, t_max=6.0)
+    n = 131072
+    outs = []
+    for _ in range(2):
+        e = Engine(DqlConfig(**kw), n, seed=515)
+        e.set_option("periods_per_launch", 4)
+        e.train_steps(40, 0.6)
+        qa, cnt = _tables(e)
+        outs.append((qa, cnt, e.states().copy(), e.stats()))
+        if len(outs) == 2:
+            st = outs[0][3]
+            assert cnt.sum() == st["decisions"] > 40 * n * 0.8 and sum(st["by_code"].values()) == st["episodes"] > 0
+            # slice: envs [lo, lo + 192) of the big engine vs an oracle shard with the same ids, both greedy on the big run's tables
+            lo, m = 70000, 192
+            reals, ints = e.get_fields()
+            orc = Oracle(DqlConfig(**kw), m, seed=515, env_id_offset=lo)
+            orc.set_option("periods_per_launch", 4)
+            orc.set_fields(reals[:, lo:lo + m], ints[:, lo:lo + m])
+            orc.step_index = e.step_index()
+            qa_f, qb_f, cnt_f = e.get_tables()
+            orc.set_tables(qa_f, qb_f, cnt_f)
+            e.eval_steps(8); orc.eval_steps(8)
+            r2, i2 = e.get_fields(); o_r, o_i = orc.get_fields()
+            np.testing.assert_array_equal(i2[:, lo:lo + m], o_i)
+            np.testing.assert_array_equal(r2[:, lo:lo + m], o_r)
+            mp_r = reals[e.field_names().index("mp_r")]
+            assert mp_r.min() >= 1.0 and mp_r.max() <= 3.0 and mp_r.std() > 0.3   # platforms really differ per env
+        e.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
