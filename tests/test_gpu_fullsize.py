@@ -124,6 +124,7 @@ def test_config5_flags_at_131072_envs(Engine):
             orc.set_option("periods_per_launch", 4)
             orc.set_fields(reals[:, lo:lo + m], ints[:, lo:lo + m])
             orc.step_index = e.step_index()
+            e.publish_tables()  # acting tables = master tables (what the oracle shard starts from)
             qa_f, qb_f, cnt_f = e.get_tables()
             orc.set_tables(qa_f, qb_f, cnt_f)
             e.eval_steps(8); orc.eval_steps(8)
