@@ -240,6 +240,20 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   return h;
 }
 
+// The same constants as instruction LITERALS, for the reference vehicle (dql_refk.inc, generated by tools/gen_refk.py): a literal costs
+// neither a register nor an SGPR operand (which halves a VALU instruction's issue rate beside other waves,
+// profiles/r2_pk_variants.jsonl).  The host selects this variant only when the context's SimK is bit-identical to the table.
+#include "dql_refk.inc"
+struct LitK {
+#define DQL_X(n, v) static constexpr float n = v;
+  DQL_REFK_SCALARS(DQL_X)
+#undef DQL_X
+#define DQL_A(n, a, b, c) static constexpr float n[3] = {a, b, c};
+  DQL_REFK_VECTORS(DQL_A)
+#undef DQL_A
+  float vz_sp, yw_sp;  // per-config set-points (training -0.1 m/s, simulation env -0.4): stay run-time values
+};
+
 enum { FL_DONE = 1, FL_CONTACT = 2, FL_ACC_INIT = 4, FL_WAS_RESET = 8, FL_OBS_CONTACT = 16 };
 enum { MODE_TRAIN = 0, MODE_EVAL = 1, MODE_EXTERNAL = 2 };
 
@@ -588,6 +602,188 @@ template <typename T> DQL_DEV T place_axis(int init_mode, T x0, T mp, T p_max) {
   return clip(x0 + mp, mp - p_max, mp + p_max);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed float32 physics tick (round 2): the same IEEE operations, component by component and in the same order, as the scalar
+// functions above (quat_to_R, yaw_cs, pid_output x 2, attitude, plant_step, rotor_filter, platform_contact) — so the CPU oracle
+// needs no change and parity stays bit-exact — but issued two at a time as v_pk_mul / v_pk_add / v_pk_fma_f32 on register PAIRS
+// that are laid out for it once per agent period: quaternion (w,x) (y,z); body rates, velocity, position (0,1) + the third
+// component; rotors by arm (0,2) (1,3); the two PIDs as one pair of controllers (v_z, yaw); platform (x,y) (u,v).  gfx950 issues a
+// wave64 f32 VALU instruction in ~4 cycles whether it does one operation per lane or two (profiles/r2_valu_rate.jsonl), so
+// every pair halves its share of the step.  Swizzles (swap, broadcast) fold into op_sel, sign flips into neg modifiers.
+// ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+DQL_DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+DQL_DEV f2 bc2(float a) { return f2{a, a}; }
+DQL_DEV f2 swp2(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+DQL_DEV f2 lo2(f2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+DQL_DEV f2 hi2(f2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+
+// Identity the optimiser cannot see through: without it the pair constructors below are merged into <2 x float> accesses of Env's
+// arrays, which overlap the 16-byte quad accesses of load_env / store_env only partially — the scalar-replacement pass then gives
+// up on the whole struct and the compiler parks it in LDS (measured: 72 B per lane, +4 us per launch)
+DQL_DEV float opq(float x) { asm("" : "+v"(x)); return x; }
+DQL_DEV double opq(double x) { return x; }
+DQL_DEV f2 mk2(float a, float b) { return f2{opq(a), opq(b)}; }
+struct TickPk {
+  f2 q_wx, q_yz, w01, v01, p01, om02, om13;
+  float w2, v2, p2;
+  f2 pid_i, pid_x1, pid_x2, pid_y1, pid_y2, pid_y3, pid_state;  // (v_z controller, yaw controller)
+  f2 mp_xy, mp_uv;
+};
+struct RotPk { f2 R04, R13, R26, R57, R01, R34, R67; float R8, cy, sy; };  // rotation matrix: symmetric partners + row pairs
+
+DQL_DEV void pack_tick(const Env<float>& e, TickPk& s) {
+  s.q_wx = mk2(e.q[0], e.q[1]); s.q_yz = mk2(e.q[2], e.q[3]);
+  s.w01 = mk2(e.w[0], e.w[1]); s.w2 = e.w[2];
+  s.v01 = mk2(e.v[0], e.v[1]); s.v2 = e.v[2];
+  s.p01 = mk2(e.p[0], e.p[1]); s.p2 = e.p[2];
+  s.om02 = mk2(e.om[0], e.om[2]); s.om13 = mk2(e.om[1], e.om[3]);
+  s.pid_i = mk2(e.vz_i, e.yw_i); s.pid_x1 = mk2(e.vz_x1, e.yw_x1); s.pid_x2 = mk2(e.vz_x2, e.yw_x2);
+  s.pid_y1 = mk2(e.vz_y1, e.yw_y1); s.pid_y2 = mk2(e.vz_y2, e.yw_y2); s.pid_y3 = mk2(e.vz_y3, e.yw_y3);
+  s.pid_state = mk2(e.vz_state, e.yw_state);
+  s.mp_xy = mk2(e.mp_x, e.mp_y); s.mp_uv = mk2(e.mp_u, e.mp_v);
+}
+DQL_DEV void unpack_tick(const TickPk& s, Env<float>& e) {
+  e.q[0] = opq(s.q_wx.x); e.q[1] = opq(s.q_wx.y); e.q[2] = opq(s.q_yz.x); e.q[3] = opq(s.q_yz.y);
+  e.w[0] = opq(s.w01.x); e.w[1] = opq(s.w01.y); e.w[2] = s.w2;
+  e.v[0] = opq(s.v01.x); e.v[1] = opq(s.v01.y); e.v[2] = s.v2;
+  e.p[0] = opq(s.p01.x); e.p[1] = opq(s.p01.y); e.p[2] = s.p2;
+  e.om[0] = opq(s.om02.x); e.om[2] = opq(s.om02.y); e.om[1] = opq(s.om13.x); e.om[3] = opq(s.om13.y);
+  e.vz_i = opq(s.pid_i.x); e.yw_i = opq(s.pid_i.y); e.vz_x1 = opq(s.pid_x1.x); e.yw_x1 = opq(s.pid_x1.y); e.vz_x2 = opq(s.pid_x2.x); e.yw_x2 = opq(s.pid_x2.y);
+  e.vz_y1 = opq(s.pid_y1.x); e.yw_y1 = opq(s.pid_y1.y); e.vz_y2 = opq(s.pid_y2.x); e.yw_y2 = opq(s.pid_y2.y); e.vz_y3 = opq(s.pid_y3.x); e.yw_y3 = opq(s.pid_y3.y);
+  e.vz_state = opq(s.pid_state.x); e.yw_state = opq(s.pid_state.y);
+  e.mp_x = opq(s.mp_xy.x); e.mp_y = opq(s.mp_xy.y); e.mp_u = opq(s.mp_uv.x); e.mp_v = opq(s.mp_uv.y);
+}
+// quat_to_R + yaw_cs
+DQL_DEV void rot_pk(const TickPk& s, RotPk& r) {
+  const f2 xy = f2{s.q_wx.y, s.q_yz.x};
+  const f2 sq = xy * xy;                                       // (xx, yy)
+  const f2 zz_xy = f2{s.q_yz.y, xy.x} * f2{s.q_yz.y, xy.y};    // (zz, xy)
+  const f2 xz_yz = xy * hi2(s.q_yz);                           // (xz, yz)
+  const f2 wx_wy = lo2(s.q_wx) * xy;                           // (wx, wy)
+  const float wz = s.q_wx.x * s.q_yz.y;
+  r.R04 = bc2(1.0f) - bc2(2.0f) * (swp2(sq) + lo2(zz_xy));     // R0 = 1 - 2 (yy + zz), R4 = 1 - 2 (xx + zz)
+  r.R8 = 1.0f - 2.0f * (sq.x + sq.y);
+  r.R13 = bc2(2.0f) * pfma(bc2(wz), f2{-1.0f, 1.0f}, hi2(zz_xy));       // 2 (xy - wz), 2 (xy + wz)
+  r.R26 = bc2(2.0f) * pfma(hi2(wx_wy), f2{1.0f, -1.0f}, lo2(xz_yz));    // 2 (xz + wy), 2 (xz - wy)
+  r.R57 = bc2(2.0f) * pfma(lo2(wx_wy), f2{-1.0f, 1.0f}, hi2(xz_yz));    // 2 (yz - wx), 2 (yz + wx)
+  r.R01 = f2{r.R04.x, r.R13.x}; r.R34 = f2{r.R13.y, r.R04.y}; r.R67 = f2{r.R26.y, r.R57.y};
+  const float R0 = r.R04.x, R3 = r.R13.y;
+  const float n2 = fma_(R0, R0, R3 * R3);
+  const float h = -0.5f * n2;
+  float rr = fma_(-0.5f, n2, 1.5f);
+#pragma unroll
+  for (int k = 0; k < YawIters<float>::n; ++k) rr = rr * fma_(h * rr, rr, 1.5f);
+  r.cy = R0 * rr; r.sy = R3 * rr;
+}
+DQL_DEV void rot_to_array(const RotPk& r, float (&R)[9]) {
+  R[0] = r.R04.x; R[1] = r.R13.x; R[2] = r.R26.x; R[3] = r.R13.y; R[4] = r.R04.y; R[5] = r.R57.x; R[6] = r.R26.y; R[7] = r.R57.y; R[8] = r.R8;
+}
+// constants of the packed tick (register pairs), built once per agent period
+struct PkK {
+  f2 kp, ki, lo, hi, wind, sp;     // the two PIDs: (v_z, yaw)
+  f2 kRn, kW01, I01, invI01;       // kRn = (kR0, -kR1)
+};
+template <typename K> DQL_DEV PkK make_pkk(const K& c) {
+  PkK k;
+  k.kp = mk2(c.vz_kp, c.yw_kp); k.ki = mk2(c.vz_ki, c.yw_ki); k.lo = mk2(c.vz_lo, c.yw_lo); k.hi = mk2(c.vz_hi, c.yw_hi);
+  k.wind = mk2(c.vz_wind, c.yw_wind); k.sp = mk2(c.vz_sp, c.yw_sp);
+  k.kRn = mk2(c.kR[0], -c.kR[1]); k.kW01 = mk2(c.kW[0], c.kW[1]); k.I01 = mk2(c.I[0], c.I[1]); k.invI01 = mk2(c.inv_I[0], c.inv_I[1]);
+  return k;
+}
+// one 500 Hz physics tick after the rotation (and the manager tick, if due): both PIDs, attitude law, rotor model, rigid body,
+// rotor filter, platform extrapolation + contact test.  B = Rx(roll_sp) Ry(pitch_sp) as pairs B01, B34, B67 and scalars B2, B5, B8.
+template <typename K>
+DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r, const f2 B01, const f2 B34, const f2 B67, const float B2,
+                             const float B5, const float B8, int& flags) {
+  // ---- pid_output x 2 (pid.py:62-104, Kd = 0) ----
+  const f2 e0 = k.sp - s.pid_state;
+  const f2 ii = s.pid_i + e0 * bc2(c.dt);
+  s.pid_i = f2{clip3(ii.x, -k.wind.x, k.wind.x), clip3(ii.y, -k.wind.y, k.wind.y)};
+  f2 acc = s.pid_x2 + bc2(2.0f) * s.pid_x1 + e0 - bc2(c.bw_k1) * s.pid_y3;
+  if (c.bw_k2 != 0) acc = acc - (bc2(c.bw_k2) * s.pid_y2);
+  const f2 fe = bc2(c.bw_inv) * acc;
+  s.pid_x2 = s.pid_x1; s.pid_x1 = e0; s.pid_y3 = s.pid_y2; s.pid_y2 = s.pid_y1; s.pid_y1 = fe;
+  const f2 eff = k.kp * fe + k.ki * s.pid_i;
+  const float thrust = clip3(eff.x, k.lo.x, k.hi.x), r_cmd = clip3(eff.y, k.lo.y, k.hi.y);
+  // ---- attitude law (attitude_controller.py:107-156) ----
+  const f2 cy2 = bc2(r.cy), sy2 = bc2(r.sy);
+  const f2 D01 = pfma(cy2, B01, -(sy2 * B34));
+  const f2 D34 = pfma(sy2, B01, cy2 * B34);
+  const f2 m25 = f2{r.sy, r.cy} * bc2(B5);                                 // (sy B5, cy B5)
+  const f2 D25 = pfma(f2{r.cy, r.sy}, bc2(B2), f2{-m25.x, m25.y});         // D2 = fma(cy, B2, -(sy B5)), D5 = fma(sy, B2, cy B5)
+  const f2 D67 = B67; const float D8 = B8;
+  // E_ij = fma(D[i], R[j], fma(D[3+i], R[3+j], D[6+i] R[6+j]))
+  const f2 E02_12 = pfma(D01, lo2(r.R26), pfma(D34, lo2(r.R57), D67 * bc2(r.R8)));          // (E02, E12)
+  const f2 E20_21 = pfma(lo2(D25), r.R01, pfma(hi2(D25), r.R34, bc2(D8) * r.R67));           // (E20, E21)
+  const f2 E01_10 = pfma(D01, swp2(r.R01), pfma(D34, swp2(r.R34), D67 * swp2(r.R67)));       // (E01, E10)
+  const float E22 = fma_(D25.x, r.R26.x, fma_(D25.y, r.R57.x, D8 * r.R8));
+  const f2 hh = bc2(0.5f) * (E02_12 - E20_21);                              // (eR1, -eR0)
+  const float eR2 = 0.5f * (E01_10.y - E01_10.x);
+  const f2 eW01 = s.w01 - bc2(r_cmd) * E02_12;
+  const float eW2 = s.w2 - r_cmd * E22;
+  const f2 M01 = swp2(hh) * k.kRn - eW01 * k.kW01;                          // (-(eR0 kR0) - eW0 kW0, -(eR1 kR1) - eW1 kW1)
+  const float M2 = -(eR2 * c.kR[2]) - eW2 * c.kW[2];
+  const float a = thrust * c.ia, cz = M2 * c.ic;
+  const f2 bxy = M01 * bc2(c.ib);
+  const f2 w2_02 = pfma(hi2(bxy), f2{-1.0f, 1.0f}, bc2(a)) + bc2(cz);      // (a - by) + cz, (a + by) + cz
+  const f2 w2_13 = pfma(lo2(bxy), f2{1.0f, -1.0f}, bc2(a)) - bc2(cz);      // (a + bx) - cz, (a - bx) - cz
+  const f2 cmd02 = f2{sqrt_(w2_02.x > 0.0f ? w2_02.x : 0.0f), sqrt_(w2_02.y > 0.0f ? w2_02.y : 0.0f)};
+  const f2 cmd13 = f2{sqrt_(w2_13.x > 0.0f ? w2_13.x : 0.0f), sqrt_(w2_13.y > 0.0f ? w2_13.y : 0.0f)};
+  // ---- rotor forces from the CURRENT rotor speeds + rigid body (gazebo_motor_model.cpp:434-500) ----
+  const float l = c.l, h = c.h;
+  const f2 q02 = s.om02 * s.om02, q13 = s.om13 * s.om13;
+  const f2 qs = q02 + q13;                                                  // (q0 + q1, q2 + q3)
+  const float Fbz = c.kf * (qs.x + qs.y);
+  const f2 qd = q02 - q13;                                                  // (q0 - q1, q2 - q3)
+  float tz = c.kmkf * (qd.x + qd.y);
+  f2 txy = bc2(c.lkf) * f2{q13.x - q13.y, q02.y - q02.x};
+  const f2 vb = pfma(r.R01, lo2(s.v01), pfma(r.R34, hi2(s.v01), r.R67 * bc2(s.v2)));
+  const f2 u = pfma(f2{s.w01.y, -s.w01.x}, bc2(h), vb);                     // (uxc, uyc)
+  const float wzl = s.w2 * l;
+  const f2 os = s.om02 + s.om13;                                            // (om0 + om1, om2 + om3)
+  const float S = os.x + os.y, d02 = s.om02.x - s.om02.y, d13 = s.om13.x - s.om13.y;
+  const f2 md = bc2(wzl) * f2{d13, d02};
+  const f2 F = -(bc2(c.cd) * pfma(bc2(S), u, f2{-md.x, md.y}));             // (Fbx, Fby)
+  const float tzd = -(c.cd * fma_(u.y, d02, fma_(wzl, S, -(u.x * d13))));
+  txy = pfma(f2{-h, h}, swp2(F), txy); tz = fma_(l, tzd, tz);
+  txy = pfma(bc2(c.crd), F, txy);
+  const float ax = fma_(r.R04.x, F.x, fma_(r.R13.x, F.y, r.R26.x * Fbz)) * c.inv_m;
+  const float ay = fma_(r.R13.y, F.x, fma_(r.R04.y, F.y, r.R57.x * Fbz)) * c.inv_m;
+  const float az = fma_(r.R26.y, F.x, fma_(r.R57.y, F.y, r.R8 * Fbz)) * c.inv_m - c.g;
+  s.v01 = pfma(bc2(c.dt), f2{ax, ay}, s.v01); s.v2 = fma_(c.dt, az, s.v2);
+  s.p01 = pfma(bc2(c.dt), s.v01, s.p01); s.p2 = fma_(c.dt, s.v2, s.p2);
+  const float w0 = s.w01.x, w1 = s.w01.y, w2 = s.w2;
+  const f2 Iw01 = k.I01 * s.w01; const float Iw2 = c.I[2] * w2;
+  const float g0 = fma_(w1, Iw2, -(w2 * Iw01.y)), g1 = fma_(w2, Iw01.x, -(w0 * Iw2)), g2 = fma_(w0, Iw01.y, -(w1 * Iw01.x));
+  s.w01 = pfma(bc2(c.dt), (txy - f2{g0, g1}) * k.invI01, s.w01);
+  s.w2 = fma_(c.dt, (tz - g2) * c.inv_I[2], w2);
+  {
+    const float qw = s.q_wx.x, qx = s.q_wx.y, qy = s.q_yz.x, qz = s.q_yz.y, hdt = 0.5f * c.dt;
+    const float nw0 = s.w01.x, nw1 = s.w01.y, nw2 = s.w2;
+    const float dw = -fma_(qx, nw0, fma_(qy, nw1, qz * nw2));
+    const float dxq = fma_(qw, nw0, fma_(qy, nw2, -(qz * nw1)));
+    const float dyq = fma_(qw, nw1, fma_(qz, nw0, -(qx * nw2)));
+    const float dzq = fma_(qw, nw2, fma_(qx, nw1, -(qy * nw0)));
+    const f2 n_wx = pfma(bc2(hdt), f2{dw, dxq}, s.q_wx), n_yz = pfma(bc2(hdt), f2{dyq, dzq}, s.q_yz);
+    const float inv = fma_(-0.5f, fma_(n_wx.x, n_wx.x, fma_(n_wx.y, n_wx.y, fma_(n_yz.x, n_yz.x, n_yz.y * n_yz.y))), 1.5f);
+    s.q_wx = n_wx * bc2(inv); s.q_yz = n_yz * bc2(inv);
+  }
+  // ---- first-order rotor speed filter (common.h:147-183), speed limit (gazebo_motor_model.cpp:358-364) ----
+  {
+    const f2 ref02 = f2{clip3(cmd02.x, 0.0f, (float)c.omax), clip3(cmd02.y, 0.0f, (float)c.omax)};
+    const f2 ref13 = f2{clip3(cmd13.x, 0.0f, (float)c.omax), clip3(cmd13.y, 0.0f, (float)c.omax)};
+    const f2 a02 = f2{ref02.x > s.om02.x ? c.aup : c.adn, ref02.y > s.om02.y ? c.aup : c.adn};
+    const f2 a13 = f2{ref13.x > s.om13.x ? c.aup : c.adn, ref13.y > s.om13.y ? c.aup : c.adn};
+    s.om02 = pfma(a02, s.om02, (bc2(1.0f) - a02) * ref02);
+    s.om13 = pfma(a13, s.om13, (bc2(1.0f) - a13) * ref13);
+  }
+  // ---- platform extrapolation between manager ticks + bumper contact test ----
+  s.mp_xy = pfma(s.mp_uv, bc2(c.dt), s.mp_xy);
+  const f2 dxy = s.p01 - s.mp_xy;
+  if (s.p2 - c.bottom <= c.mp_top && abs_(dxy.x) <= c.mp_hx && abs_(dxy.y) <= c.mp_hy) flags |= FL_CONTACT;
+}
+
 struct StepOut {  // what one env contributes to the shared tables / counters this period
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
   long long target_y_fx;
@@ -736,17 +932,29 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
   return out;
 }
 
+#ifndef DQL_TICK_UNROLL
+#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves); 3, 4, 6 are worse
+#endif
+#ifndef DQL_GROUP
+#define DQL_GROUP 5  // manager_div of the reference: 500 Hz physics / 100 Hz observation (SURVEY.md appendix A)
+#endif
 // One agent period of one env in one lane.  HOT: hold the per-tick constants in VGPRs (small batches: one wave per SIMD,
 // registers are free and every avoided v_readlane shortens the dependency-bound stream; at full occupancy it costs a wave).
-template <bool HOT, typename T> struct HotSel { static DQL_DEV const SimK<T>& get(const SimK<T>& s) { return s; } };
-template <> struct HotSel<true, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
-template <bool HOT, typename T, typename TabPtr>
+// TICK: 0 plain loop on SGPR constants, 1 per-tick constants in VGPRs + the loop laid out per manager period, 2 the same with the
+// packed float32 tick (physics_tick_pk), 3 plain loop with the reference vehicle's constants as literals (LitK)
+enum { TICK_PLAIN = 0, TICK_LONE = 1, TICK_PACKED = 2, TICK_LIT = 3 };
+template <int TICK, typename T> struct TickK { static DQL_DEV const SimK<T>& get(const SimK<T>& s) { return s; } };
+template <> struct TickK<TICK_LONE, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
+template <> struct TickK<TICK_PACKED, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
+template <> struct TickK<TICK_LIT, float> { static DQL_DEV LitK get(const SimK<float>& s) { return LitK{s.vz_sp, s.yw_sp}; } };
+template <int TICK, typename T, typename TabPtr>
 DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
                              int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
   T B[9];
   make_B(e.pitch_sp, e.roll_sp, B);
-  const auto h = HotSel<HOT, T>::get(s);
+  constexpr bool HOT = TICK == TICK_LONE || TICK == TICK_PACKED;
+  const auto h = TickK<TICK, T>::get(s);
   DQL_MARK_T(e, 3);
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
@@ -771,11 +979,59 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     DQL_SECTION("platform_contact");
     platform_contact(h, e);
   };
-  if constexpr (!(HOT && sizeof(T) == 4)) {
+  if constexpr (sizeof(T) == 4 && TICK == TICK_PACKED) {
+    // float32: the packed tick (physics_tick_pk): the state the 500 Hz loop touches lives in register pairs for the whole period
+    TickPk ts;
+    pack_tick(e, ts);
+    const PkK pk = make_pkk(h);
+    const f2 B01 = f2{B[0], B[1]}, B34 = f2{B[3], B[4]}, B67 = f2{B[6], B[7]};
+    const float B2 = B[2], B5 = B[5], B8 = B[8];
+    RotPk rp;
+    auto tick_pk = [&](bool mgr) {
+      DQL_SECTION("rot");
+      rot_pk(ts, rp);
+      if (mgr) {
+        e.p[0] = opq(ts.p01.x); e.p[1] = opq(ts.p01.y); e.p[2] = ts.p2; e.v[0] = opq(ts.v01.x); e.v[1] = opq(ts.v01.y); e.v[2] = ts.v2;
+        e.mp_x = opq(ts.mp_xy.x); e.mp_y = opq(ts.mp_xy.y); e.mp_u = opq(ts.mp_uv.x); e.mp_v = opq(ts.mp_uv.y);
+        {
+          DQL_SECTION("manager");
+          float Rm[9];  // scoped: a long-lived array would be demoted to LDS by the compiler
+          rot_to_array(rp, Rm);
+          manager_states(Rm, rp.cy, rp.sy, e.v[2], e.vz_state, e.yw_state);
+          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
+          ++mgr_in_step; ++mgr_index;
+        }
+        ts.pid_state = mk2(e.vz_state, e.yw_state); ts.mp_xy = mk2(e.mp_x, e.mp_y); ts.mp_uv = mk2(e.mp_u, e.mp_v);
+      }
+      DQL_SECTION("tick_pk");
+      physics_tick_pk(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
+    };
+    if constexpr (!HOT) {
+#pragma unroll DQL_TICK_UNROLL
+      for (int i = 0; i < n_ticks; ++i) {
+        tick_pk(phase == 0);
+        phase = (phase + 1 == s.div) ? 0 : phase + 1;
+      }
+    } else {
+      int left = n_ticks;
+      for (;;) {
+        while (left > 0 && !(s.div == DQL_GROUP && phase == 0 && left >= DQL_GROUP)) {
+          tick_pk(phase == 0);
+          phase = (phase + 1 == s.div) ? 0 : phase + 1;
+          --left;
+        }
+        if (left == 0) break;
+        do {
+          tick_pk(true);
+#pragma unroll
+          for (int k = 1; k < DQL_GROUP; ++k) tick_pk(false);
+          left -= DQL_GROUP;
+        } while (left >= DQL_GROUP);
+      }
+    }
+    unpack_tick(ts, e);
+  } else if constexpr (!(HOT && sizeof(T) == 4)) {
     // big batches (several waves per SIMD, registers decide the occupancy): the plain loop
-#ifndef DQL_TICK_UNROLL
-#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves); 3, 4, 6 are worse
-#endif
 #pragma unroll DQL_TICK_UNROLL
     for (int i = 0; i < n_ticks; ++i) {
       DQL_SECTION("rot");
@@ -789,9 +1045,6 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     // tick, then whole manager periods (one manager tick + DQL_GROUP physics ticks, straight-line: no phase test, the filter
     // histories rotate by renaming instead of moves), then the rest.  Same operations in the same order as the plain loop,
     // which still serves any other manager_div.  Measured: -4 % at 4 096 envs.
-#ifndef DQL_GROUP
-#define DQL_GROUP 5  // manager_div of the reference: 500 Hz physics / 100 Hz observation (SURVEY.md appendix A)
-#endif
     int left = n_ticks;
     for (;;) {
       while (left > 0 && !(s.div == DQL_GROUP && phase == 0 && left >= DQL_GROUP)) {
@@ -857,21 +1110,21 @@ template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict
 }
 template <typename T> DQL_DEV void store_env(const Env<T>& e, Quad<T>* __restrict__ sr, int4* __restrict__ si, long long n, long long i,
                                              const SimK<T>& c) {
-  sr[0 * n + i] = Quad<T>{e.p[0], e.p[1], e.p[2], e.v[0]};
-  sr[1 * n + i] = Quad<T>{e.v[1], e.v[2], e.q[0], e.q[1]};
-  sr[2 * n + i] = Quad<T>{e.q[2], e.q[3], e.w[0], e.w[1]};
-  sr[3 * n + i] = Quad<T>{e.w[2], e.om[0], e.om[1], e.om[2]};
-  sr[4 * n + i] = Quad<T>{e.om[3], e.vz_i, e.vz_x1, e.vz_x2};
-  sr[5 * n + i] = Quad<T>{e.vz_y1, e.vz_y2, e.vz_y3, e.vz_state};
-  sr[6 * n + i] = Quad<T>{e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1};
-  sr[7 * n + i] = Quad<T>{e.yw_y2, e.yw_y3, e.yw_state, e.pitch_sp};
-  sr[8 * n + i] = Quad<T>{e.mp_phase, e.mp_x, e.mp_u, e.vf_x};
-  sr[9 * n + i] = Quad<T>{e.kal_x_x, e.kal_x_P, e.shp_p, e.shp_v};
-  sr[10 * n + i] = Quad<T>{e.shp_a, e.cum_x, e.roll_sp, e.mp_y};
-  if (c.two_axis || c.traj == DQL_TRAJ_EIGHT) sr[11 * n + i] = Quad<T>{e.mp_v, e.vf_y, e.kal_y_x, e.kal_y_P};
-  if (c.two_axis) sr[12 * n + i] = Quad<T>{e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y};
-  sr[14 * n + i] = Quad<T>{e.reward, e.obs_px, e.obs_vx, e.obs_ax};
-  sr[15 * n + i] = Quad<T>{e.obs_py, e.obs_vy, e.obs_ay, T(0.0)};
+  sr[0 * n + i] = Quad<T>{opq(e.p[0]), opq(e.p[1]), opq(e.p[2]), opq(e.v[0])};
+  sr[1 * n + i] = Quad<T>{opq(e.v[1]), opq(e.v[2]), opq(e.q[0]), opq(e.q[1])};
+  sr[2 * n + i] = Quad<T>{opq(e.q[2]), opq(e.q[3]), opq(e.w[0]), opq(e.w[1])};
+  sr[3 * n + i] = Quad<T>{opq(e.w[2]), opq(e.om[0]), opq(e.om[1]), opq(e.om[2])};
+  sr[4 * n + i] = Quad<T>{opq(e.om[3]), opq(e.vz_i), opq(e.vz_x1), opq(e.vz_x2)};
+  sr[5 * n + i] = Quad<T>{opq(e.vz_y1), opq(e.vz_y2), opq(e.vz_y3), opq(e.vz_state)};
+  sr[6 * n + i] = Quad<T>{opq(e.yw_i), opq(e.yw_x1), opq(e.yw_x2), opq(e.yw_y1)};
+  sr[7 * n + i] = Quad<T>{opq(e.yw_y2), opq(e.yw_y3), opq(e.yw_state), opq(e.pitch_sp)};
+  sr[8 * n + i] = Quad<T>{opq(e.mp_phase), opq(e.mp_x), opq(e.mp_u), opq(e.vf_x)};
+  sr[9 * n + i] = Quad<T>{opq(e.kal_x_x), opq(e.kal_x_P), opq(e.shp_p), opq(e.shp_v)};
+  sr[10 * n + i] = Quad<T>{opq(e.shp_a), opq(e.cum_x), opq(e.roll_sp), opq(e.mp_y)};
+  if (c.two_axis || c.traj == DQL_TRAJ_EIGHT) sr[11 * n + i] = Quad<T>{opq(e.mp_v), opq(e.vf_y), opq(e.kal_y_x), opq(e.kal_y_P)};
+  if (c.two_axis) sr[12 * n + i] = Quad<T>{opq(e.shpy_p), opq(e.shpy_v), opq(e.shpy_a), opq(e.cum_y)};
+  sr[14 * n + i] = Quad<T>{opq(e.reward), opq(e.obs_px), opq(e.obs_vx), opq(e.obs_ax)};
+  sr[15 * n + i] = Quad<T>{opq(e.obs_py), opq(e.obs_vy), opq(e.obs_ay), T(0.0)};
   si[i] = make_int4(e.idx_x, e.idx_y, (e.step_count & 0xffff) | (e.cur_check << 16), (e.code & 0xff) | ((e.flags & 0xff) << 8) | ((e.action & 0xff) << 16));
 }
 

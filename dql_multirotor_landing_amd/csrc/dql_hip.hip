@@ -59,6 +59,17 @@ template <typename T> static MdpK<T> make_mdpk(const dql_config& c) {
   d.gamma = c.gamma; d.working = c.working_curriculum_step; d.goal_logic = c.goal_logic; d.quirks = c.quirks;
   return d;
 }
+// is this SimK the table k_step<float, ., TICK_LIT> was compiled with?  (bit for bit; -0.0 != +0.0 on purpose)
+static bool refk_matches(const SimK<float>& s) {
+  bool ok = true;
+#define DQL_X(n, v) { const float r = v; ok = ok && memcmp(&s.n, &r, sizeof(float)) == 0; }
+  DQL_REFK_SCALARS(DQL_X)
+#undef DQL_X
+#define DQL_A(n, a, b, c) { const float r[3] = {a, b, c}; ok = ok && memcmp(s.n, r, sizeof(r)) == 0; }
+  DQL_REFK_VECTORS(DQL_A)
+#undef DQL_A
+  return ok;
+}
 template <typename T> static SimK<T> make_simk(const dql_config& c) {
   SimK<T> d;
   memset(&d, 0, sizeof(d));
@@ -193,12 +204,6 @@ DQL_DEV long long wave_sum(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);  // wave-uniform
 }
 
-#ifndef DQL_LONE_MAX
-#define DQL_LONE_MAX 262144  // measured (profiles/r1_sweep_envs.jsonl): the lone-wave layout wins up to 262 144 envs, the plain loop from 524 288
-#endif
-#ifndef DQL_WAVES_PER_EU
-#define DQL_WAVES_PER_EU 1
-#endif
 // The step kernel's arguments (constants by value: ~0.5 KB = 8 cache lines) are fetched by the compiler piecemeal, one scalar
 // load + wait per line as registers allow: a chain of scalar-cache misses at the head of every wave.  Touch all lines at once
 // first; the later loads then hit the scalar cache.
@@ -222,7 +227,10 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
 // LONE: the register-hungry layout (per-tick constants in VGPRs, tick loop laid out per manager period: dql_device.hpp,
 // agent_period) for batches of at most a couple of waves per SIMD.  Every instantiation is capped at 2 waves per SIMD: measured
 // at 1 M envs, 3 resident waves are 7 % slower than 2 (and 4 no better), so the allocator may as well keep its registers.
-template <typename T, int BLOCK, bool LONE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_step(StepArgs<T> a) {
+// 64 .. 256 threads: at most 2 waves per SIMD (68 KB of LDS accumulators per workgroup, or the register-hungry layouts); 512 threads:
+// two workgroups per CU = 4 waves per SIMD, so the compiler must stay within 128 VGPRs (it parks ~35 cold values in scratch)
+constexpr int step_waves_per_simd(int block) { return block == 512 ? 4 : 2; }
+template <typename T, int BLOCK, int LONE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
@@ -502,6 +510,8 @@ struct dql_ctx {
   int sync_period = 1;
   bool windowed = false;
   int block = 0;  // 0 = auto
+  int tick = 0;   // 0 = auto, 1 plain loop, 2 VGPR constants + grouped loop, 3 packed float32 tick, 4 literal constants (reference vehicle)
+  bool lit_ok = false;  // float32 and the tick constants are bit-identical to dql_refk.inc
   unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
   int elog_cap = 0, elog_n = 0;
   uint8_t* d_mask = nullptr;     // reset mask staging (dql_reset), allocated on first use
@@ -564,19 +574,43 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
   return a;
 }
-template <typename T, int BLOCK, bool LONE> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
+template <typename T, int BLOCK, int LONE> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
   const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK, n_periods);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL((k_step<T, BLOCK, LONE>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
+// Which k_step variant serves a launch (options "block" and "tick"; 0 = auto).  Measured on MI355X, periods_per_launch 4
+// (profiles/r2_sweep_tick.jsonl, r2_sweep_occupancy.jsonl):
+//   block  64 (no LDS staging, one wave per workgroup) up to 8 192 envs; 256 (2 waves per SIMD) up to 131 072; 512 with the register
+//          budget of 4 waves per SIMD from 262 144 envs (float32: -3 % plain, -6 % with literal constants at 1 M envs)
+//   tick   packed float32 tick while a SIMD hosts at most one env wave (<= 65 536 envs: 18.7 vs 20.2 us at 4 096, 20.8 vs 22.3 at
+//          32 768; beside a second wave a packed instruction costs two issue slots and the layout LOSES: 45 vs 36 us at 131 072);
+//          literal constants with the 512-thread block when the vehicle is the reference's; the plain loop otherwise.
+//          2 (VGPR constants + grouped loop, the small-batch layout of round 1) is kept as an option only.
+// float64 has one layout (no packed f64 pipe to use, no 64-bit literals): plain.
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps, int np) {
-  // measured on MI355X (profiles/r1_sweep_blocks.jsonl): single-wave workgroups up to 8192 envs, 256 threads above
-  int block = x->block;
-  if (block == 0) block = (x->n <= 8192) ? 64 : 256;
-  const bool lone = x->n <= DQL_LONE_MAX;
-  if (block == 64) { if (lone) launch_step_t<T, 64, true>(x, mode, eps, np); else launch_step_t<T, 64, false>(x, mode, eps, np); }
-  else if (block == 128) launch_step_t<T, 128, false>(x, mode, eps, np);
-  else { if (lone) launch_step_t<T, 256, true>(x, mode, eps, np); else launch_step_t<T, 256, false>(x, mode, eps, np); }
+  int block = x->block, tick = x->tick;
+  if constexpr (sizeof(T) == 8) {
+    if (block == 0) block = (x->n <= 8192) ? 64 : 256;
+    if (block == 64) launch_step_t<T, 64, TICK_PLAIN>(x, mode, eps, np);
+    else if (block == 128) launch_step_t<T, 128, TICK_PLAIN>(x, mode, eps, np);
+    else launch_step_t<T, 256, TICK_PLAIN>(x, mode, eps, np);
+  } else {
+    if (block == 0) block = (x->n <= 8192) ? 64 : (x->n < 262144 || tick == 2 || tick == 3 ? 256 : 512);
+    if (tick == 0) tick = x->n <= 65536 ? 3 : (block == 512 && x->lit_ok ? 4 : 1);
+    if (tick == 4 && !x->lit_ok) tick = 1;
+    if (block == 128 || (block == 512 && tick != 4)) tick = 1;
+    if (tick == 4) {
+      if (block == 64) launch_step_t<T, 64, TICK_LIT>(x, mode, eps, np); else if (block == 512) launch_step_t<T, 512, TICK_LIT>(x, mode, eps, np);
+      else launch_step_t<T, 256, TICK_LIT>(x, mode, eps, np);
+    } else if (block == 512) launch_step_t<T, 512, TICK_PLAIN>(x, mode, eps, np);
+    else if (block == 128) launch_step_t<T, 128, TICK_PLAIN>(x, mode, eps, np);
+    else if (block == 64) {
+      if (tick == 3) launch_step_t<T, 64, TICK_PACKED>(x, mode, eps, np); else if (tick == 2) launch_step_t<T, 64, TICK_LONE>(x, mode, eps, np); else launch_step_t<T, 64, TICK_PLAIN>(x, mode, eps, np);
+    } else {
+      if (tick == 3) launch_step_t<T, 256, TICK_PACKED>(x, mode, eps, np); else if (tick == 2) launch_step_t<T, 256, TICK_LONE>(x, mode, eps, np); else launch_step_t<T, 256, TICK_PLAIN>(x, mode, eps, np);
+    }
+  }
 }
 // ONE kernel per launch of n_periods (1 .. periods_per_launch) agent periods
 static int launch_period(dql_ctx* x, int mode, double eps, int n_periods = 1) {
@@ -704,6 +738,7 @@ static int create_impl(dql_ctx* x, const dql_config* cfg) {
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } while (0)
   HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&x->ev0)); HIP_TRY(hipEventCreate(&x->ev1));
+  x->lit_ok = cfg->dtype == DQL_F32 && refk_matches(make_simk<float>(*cfg));
   ALLOC(x->sr, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size);
   ALLOC(x->si, (size_t)x->n * sizeof(int4));
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
@@ -1182,7 +1217,18 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
     x->periods_per_launch = value;
     return DQL_OK;
   }
-  if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(DQL_EINVAL, "block must be 0, 64, 128 or 256"); x->block = value; return DQL_OK; }
+  if (!strcmp(name, "tick")) {
+    if (value < 0 || value > 4) return fail(DQL_EINVAL, "tick must be 0 (auto), 1 (plain), 2 (VGPR constants), 3 (packed float32) or 4 (literal constants)");
+    if (value == 4 && !x->lit_ok) return fail(DQL_EINVAL, "tick 4 serves float32 contexts whose vehicle / controller constants are the reference's (tools/gen_refk.py); this context's differ");
+    x->tick = value;
+    return DQL_OK;
+  }
+  if (!strcmp(name, "block")) {
+    if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512) return fail(DQL_EINVAL, "block must be 0, 64, 128, 256 or 512");
+    if (value == 512 && x->dtype != DQL_F32) return fail(DQL_EINVAL, "block 512 serves float32 contexts");
+    x->block = value;
+    return DQL_OK;
+  }
   return fail(DQL_EINVAL, std::string("unknown option ") + name);
 }
 

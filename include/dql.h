@@ -256,7 +256,10 @@ int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
 int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
 /* holds the context's stream for this long (a one-wave timer kernel): phase offset between contexts that share a GPU */
 int dql_delay(dql_ctx* ctx, double microseconds);
-/* knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup);
+/* knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup; 512 = float32 at 4 waves per SIMD); "tick" (0 = auto; layout of the
+ * 500 Hz loop: 1 plain loop on scalar-register constants, 2 constants in vector registers + loop laid out per manager period, 3 the
+ * packed float32 tick, 4 constants as instruction literals — float32 contexts whose vehicle / controller constants are the
+ * reference's, DQL_EINVAL otherwise: same arithmetic, bit for bit, in all);
  * "periods_per_launch" P in 1..4 (default 1): dql_train_steps / dql_eval_steps run P agent periods per kernel launch — every env
  * stays in registers between them, so the state round trip through HBM and the launch boundary are paid once per P periods.
  * Table timing in units of launches is unchanged (a launch acts on every accumulator up to the launch before the previous one,

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): discrete state indices, actions and tables bit-e
 1e-5 relative.  Because oracle and kernel spell out the same IEEE-754 operation sequence (explicit fma, no
 contraction, own elementary functions), the same-dtype comparison is asserted EXACT for every field; the 1e-5 bound
 is what the float32 kernel must hold against the float64 oracle over one agent period from identical states."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -329,6 +331,47 @@ def test_double_q_learning_updates_both_tables_in_paper_mode(mods):
         assert acc.shape == (4 * 2835,) and np.array_equal(acc, orc.get_accum()) and acc[2 * 2835:].any()
         eng.apply_accum(); orc.flush(); orc.apply_accum()
         _compare(eng, orc, exact=True, what="windowed double Q")
+
+
+@pytest.mark.parametrize("tick,block,kw", [(1, 0, {}), (2, 0, {}), (2, 256, {}), (3, 64, {}), (3, 256, {}), (4, 0, {}), (4, 64, {}), (4, 512, {}), (1, 512, {}),
+                                           (0, 512, dict(two_axis=1, trajectory=TRAJ_EIGHT)), (4, 512, dict(vz_setpoint=-0.4, working_curriculum_step=3, init_uniform=1)),
+                                           (3, 0, dict(two_axis=1, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1))])
+def test_tick_layouts_bit_exact(mods, tick, block, kw):
+    """Options "tick" / "block": every layout of the 500 Hz loop (plain, VGPR constants, packed float32, literal constants) and every
+    workgroup size (64 .. 512 threads, the last with the register budget of 4 waves per SIMD: cold values in scratch) computes the
+    same bits as the oracle.  n spans full and ragged workgroups; 3 periods per launch; episodes end inside launches."""
+    Engine, Oracle = mods
+    n = 1100
+    cfg = dict(dtype=F32, t_max=4.0, **kw)
+    eng = Engine(DqlConfig(**cfg), n, seed=21); orc = Oracle(DqlConfig(**cfg), n, seed=21, n_threads=8)
+    eng.set_option("tick", tick); eng.set_option("block", block)
+    eng.set_option("periods_per_launch", 3); orc.set_option("periods_per_launch", 3)
+    g = Path(__file__).parent / "golden" / "assets"
+    qa, qb, cnt = (np.load(g / f) for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"))
+    eng.set_tables(qa, qb, cnt); orc.set_tables(qa, qb, cnt)
+    for steps, eps in ((100, 0.3), (50, 0.0)):
+        eng.train_steps(steps, eps); orc.train_steps(steps, eps)
+        _compare(eng, orc, exact=True, what=f"tick={tick} block={block} {kw}")
+    assert eng.stats()["episodes"] > n // 2
+
+
+def test_literal_tick_needs_reference_vehicle(mods):
+    """tick 4 is compiled with the reference vehicle's constants as literals (csrc/dql_refk.inc): a context whose constants differ
+    in any bit refuses the option, and its automatic choice falls back to run-time constants — checked against the oracle."""
+    Engine, Oracle = mods
+    cfg = dict(dtype=F32, mass=0.75, t_max=4.0)
+    eng = Engine(DqlConfig(**cfg), 700, seed=2); orc = Oracle(DqlConfig(**cfg), 700, seed=2)
+    with pytest.raises(ValueError):
+        eng.set_option("tick", 4)
+    eng.set_option("block", 512)
+    eng.train_steps(60, 0.5); orc.train_steps(60, 0.5)
+    _compare(eng, orc, exact=True, what="modified vehicle, block 512")
+    e64 = Engine(DqlConfig(dtype=F64), 64, seed=2)
+    with pytest.raises(ValueError):
+        e64.set_option("block", 512)
+    with pytest.raises(ValueError):
+        e64.set_option("tick", 4)
+    Engine(DqlConfig(dtype=F32), 64, seed=2).set_option("tick", 4)  # the default config IS the reference vehicle
 
 
 @pytest.mark.parametrize("P,n,block,kw", [(2, 4096, 0, {}), (3, 300, 64, dict(quirks=Q_PAPER, fold_per_step=1)), (4, 9000, 256, dict(t_max=3.0)),

@@ -235,3 +235,14 @@ def test_trainer_ordered_promotion_and_budget(tmp_path, monkeypatch):
                    initial_curriculum_step=1, judge_envs=50)
     hist = tr.curriculum_training()
     assert [h["level"] for h in hist] == [1] and not hist[0]["promoted"] and not hist[0]["exhausted"]
+
+
+def test_reference_vehicle_literal_table_is_current():
+    """csrc/dql_refk.inc (the constants k_step's literal-constant variant is compiled with) is what tools/gen_refk.py derives from
+    DqlConfig() today.  A stale table could not change a result (the library compares bit for bit before choosing the variant) but
+    would silently switch the variant off for the reference's own parameter set."""
+    import importlib.util
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("gen_refk", root / "tools" / "gen_refk.py")
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert (root / "dql_multirotor_landing_amd" / "csrc" / "dql_refk.inc").read_text() == m.render()
