@@ -357,8 +357,17 @@ def main():
 
 
 def valu_roofline(args, k_ms):
-    """The roof that actually binds: wave64 f32 VALU instructions through 1024 SIMDs (tools/micro/valu_rate.hip prices one), with
-    the instruction count per env wave from the committed PMC pass."""
+    """The roof that actually binds: wave64 VALU instructions through 1024 SIMDs, with the instruction count per env wave from the
+    committed PMC pass (profiles/r2_pmc_sq_summary.json) and issue costs per instruction FORM from the asm micro benchmarks
+    (tools/micro/pk_variants.hip, valu_forms.hip -> profiles/r2_pk_variants.jsonl, r2_valu_forms.jsonl; placement verified from HW_ID).
+    What those found on this chip (2.3-2.4 GHz shader clock):
+      >= 2 waves per SIMD:  v_fma / v_mul / v_add / v_mov / v_and with VGPR or literal sources 0.95-1.25 ns (the guide's "2 cycles" row,
+                            2.3-3 cycles measured); ANY SGPR source operand 1.8-1.95 ns; compares, selects, min / max / med3, conversions,
+                            integer ops 1.7-1.9 ns (4 cycles); v_pk_*_f32 1.9-2.1 ns (two operations: no gain); v_sqrt / v_rcp 3.5 ns
+      one wave per SIMD:    every form 1.85-2.45 ns (the wave's own issue interval), v_pk_*_f32 2.4-2.6 ns (two operations: the gain the
+                            packed tick of small batches lives on), v_sqrt / v_rcp 3.6-3.9 ns
+    Three prices per launch: every instruction at the full-rate form's cost ("all_full_rate": no kernel with compares and selects can
+    reach it), the kernel's own mix of forms in the tick loop (tools/isa_sections.py, "own_mix"), and MI355X_MICROARCH.md's table row."""
     if args.two_axis or args.dtype != "f32":
         return None
     pf = ROOT / "profiles" / "r2_pmc_sq_summary.json"
@@ -371,16 +380,15 @@ def valu_roofline(args, k_ms):
         return None
     valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * P  # per launch
     waves = (args.envs + 63) // 64
-    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "source": f"profiles/{pf.name}"}
-    # two prices per wave64 f32 VALU instruction per SIMD: what tools/micro/valu_rate.hip measures on this chip with the placement
-    # verified (profiles/r2_valu_rate.jsonl: 4.64 cycles for a lone wave with instruction-level parallelism, 4.06-4.3 with 2-8 waves,
-    # at 2.3-2.4 GHz), and MI355X_MICROARCH.md's table row (2 cycles with >= 2 waves per SIMD, 4 for a lone wave; reached on this
-    # chip only by packed v_pk_fma_f32, which does two FMAs in those 4 cycles)
     lone = waves <= 1024
-    for tag, ns in (("measured_micro", 1.94 if lone else 1.74), ("guide_table", (4 if lone else 2) / 2.4)):
+    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
+           "source": f"profiles/{pf.name} (instruction count), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
+    prices = (("all_full_rate", 2.2 if lone else 1.15), ("own_mix", 2.3 if lone else 1.40), ("guide_table", (4 if lone else 2) / 2.4))
+    for tag, ns in prices:
         floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)
         out[tag] = {"ns_per_wave64_valu_instr_per_simd": ns, "floor_ms_per_launch": floor_s * 1e3, "frac": floor_s * 1e3 / k_ms if k_ms > 0 else None}
-    out["note"] = "informational: the fused step is bound by VALU issue (one wave's instruction stream at small batches, all SIMDs busy at large ones), not by HBM"
+    out["note"] = ("informational: the fused step is bound by VALU issue (one wave's own instruction stream at small batches, all SIMDs busy at large ones), "
+                   "not by HBM; frac = floor / measured launch time")
     return out
 
 

@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned long long real_clock() { unsigned long long 
     float x0 = threadIdx.x * 1e-3f, x1 = threadIdx.x * 2e-3f, x2 = threadIdx.x * 3e-3f, x3 = threadIdx.x * 4e-3f;           \
     const unsigned long long r0 = real_clock();                                                                              \
     for (int i = 0; i < iters; ++i)                                                                                          \
-      asm volatile(R16(G) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207"); \
+      asm volatile(R16(G) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207"); \
     const unsigned long long r1 = real_clock();                                                                              \
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;                                                           \
     if ((threadIdx.x & 63) == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));         \

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes of tools/prof_run.py -> profiles/r2_pmc_sq_summary.json and profiles/r2_traffic.json.
+
+    python tools/pmc_summary.py gpurun_out/<dir> ...        # dirs named pmc_<sq|fetch|write>_<envs>_p<P>
+Every pass is its own run (`rocprofv3 --kernel-trace --pmc ... -- python3 tools/prof_run.py N S 0 P`); per-launch averages of
+k_step over launches 6..N (the first launches hold the reset period).  Units and the gfx950 correction follow
+MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 reports half of a wide
+coalesced read stream), WRITE_SIZE as is."""
+import csv, glob, json, re, sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sq, tr = {}, defaultdict(dict)
+for d in sys.argv[1:]:
+    m = re.search(r"pmc_(sq|fetch|write)_(\d+)_p(\d+)$", d.rstrip("/"))
+    kind, envs, P = m.group(1), int(m.group(2)), int(m.group(3))
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    per = defaultdict(list); kname = None
+    for r in csv.DictReader(open(f)):
+        if "k_step" in r["Kernel_Name"]:
+            per[r["Counter_Name"]].append(float(r["Counter_Value"])); kname = r["Kernel_Name"]
+    key = f"{envs}_p{P}"
+    if kind == "sq":
+        c = {k: sum(v[5:]) / len(v[5:]) for k, v in per.items()}
+        c.update(periods_per_launch=P, launches_averaged=len(next(iter(per.values()))) - 5, kernel=kname,
+                 SQ_INSTS_VALU_per_env_wave_per_period=c["SQ_INSTS_VALU"] / ((envs + 63) // 64) / P,
+                 note="per launch, summed over all waves incl. the table-writer workgroups")
+        sq[key] = c
+    else:
+        name = "FETCH_SIZE" if kind == "fetch" else "WRITE_SIZE"
+        v = per[name][5:]
+        tr[key][f"{name}_KiB_raw_per_launch"] = sum(v) / len(v)
+        tr[key].update(envs=envs, periods_per_launch=P, kernel=kname)
+for key, c in tr.items():
+    if "FETCH_SIZE_KiB_raw_per_launch" not in c or "WRITE_SIZE_KiB_raw_per_launch" not in c:
+        continue
+    n = c["envs"] * c["periods_per_launch"]
+    c["read_bytes_per_launch"] = 2 * 1024 * c["FETCH_SIZE_KiB_raw_per_launch"]
+    c["write_bytes_per_launch"] = 1024 * c["WRITE_SIZE_KiB_raw_per_launch"]
+    c["hbm_bytes_per_launch"] = c["read_bytes_per_launch"] + c["write_bytes_per_launch"]
+    c["read_bytes_per_env_step"] = c["read_bytes_per_launch"] / n
+    c["write_bytes_per_env_step"] = c["write_bytes_per_launch"] / n
+    c["hbm_bytes_per_env_step"] = c["hbm_bytes_per_launch"] / n
+    c["ratio_to_algorithmic_320B"] = c["hbm_bytes_per_env_step"] / 320.0
+if sq:
+    (ROOT / "profiles" / "r2_pmc_sq_summary.json").write_text(json.dumps(dict(sorted(sq.items())), indent=1))
+if tr:
+    (ROOT / "profiles" / "r2_traffic.json").write_text(json.dumps({
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), tools/prof_run.py N S 0 P, kernel k_step, averages over launches 6..N",
+        "units": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read stream); WRITE_SIZE taken as is; per env-step = per launch / (envs x periods per launch)",
+        "configs": dict(sorted(tr.items()))}, indent=1))
+print("sq:", sorted(sq), "traffic:", sorted(tr))
