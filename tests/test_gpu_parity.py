@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): discrete state indices, actions and tables bit-e
 1e-5 relative.  Because oracle and kernel spell out the same IEEE-754 operation sequence (explicit fma, no
 contraction, own elementary functions), the same-dtype comparison is asserted EXACT for every field; the 1e-5 bound
 is what the float32 kernel must hold against the float64 oracle over one agent period from identical states."""
+import os
 from pathlib import Path
 
 import numpy as np
@@ -239,6 +240,79 @@ def test_rccl_reducer_world_size_1():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_RCCL_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from dql_multirotor_landing_amd.comm import RcclComm
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.dist import RcclWindowReducer, ShardedRunner, shard_range
+from dql_multirotor_landing_amd.engine import Engine
+n_total, out = int(sys.argv[1]), sys.argv[2]
+comm = RcclComm.from_env()                      # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as a launcher exports them
+lo, hi = shard_range(n_total, comm.rank, comm.world)
+eng = Engine(DqlConfig(dtype=F32), hi - lo, seed=42, device=comm.device, env_id_offset=lo)
+eng.set_option("periods_per_launch", 2)
+run = ShardedRunner(eng, RcclWindowReducer(eng, comm), sync_period=2)
+run.train_steps(40, 1.0); run.train_steps(40, 0.2); run.sync()
+qa, qb, cnt = eng.get_tables()
+reals, ints = eng.get_fields()
+dec = comm.all_reduce_sum([float(eng.stats()["decisions"])])[0]
+np.savez(f"{out}/rank{comm.rank}.npz", qa=qa, qb=qb, count=cnt, reals=reals, ints=ints, decisions=dec)
+comm.barrier(); comm.close()
+assert "torch" not in sys.modules
+print("RANK_OK")
+"""
+
+
+def test_rccl_two_ranks_equal_one_process(tmp_path):
+    """Two ranks on two GPUs, table exchange by ncclAllReduce(int64, sum) from inside libdql_hip.so every 2 agent periods ==
+    one process with all the envs on the same schedule (the local exchange), bit for bit: tables, visit counts and every env's
+    state (integer sums are order independent, the RNG is keyed by the global env id).  Needs 2 GPUs: skipped on a 1-GPU box,
+    where tests/test_dist_gloo.py covers the same runner with a gloo stand-in communicator."""
+    import ctypes as C
+    import socket
+    import subprocess
+    import sys
+    from dql_multirotor_landing_amd import _lib
+    from dql_multirotor_landing_amd.dist import LocalWindowReducer, ShardedRunner
+    from dql_multirotor_landing_amd.engine import Engine
+    n = C.c_int(0)
+    _lib.check(_lib.load().dql_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("needs 2 GPUs")
+    root = Path(__file__).resolve().parent.parent
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    n_total = 6000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _RCCL_RANK_SCRIPT, str(n_total), str(tmp_path)], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=600))
+    finally:
+        for pr in procs:  # exactly the processes started here
+            if pr.poll() is None:
+                pr.kill()
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0 and "RANK_OK" in so, so[-1000:] + se[-3000:]
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    single = Engine(DqlConfig(dtype=F32), n_total, seed=42)
+    single.set_option("periods_per_launch", 2)
+    run = ShardedRunner(single, LocalWindowReducer(single), sync_period=2)
+    run.train_steps(40, 1.0); run.train_steps(40, 0.2); run.sync()
+    qa, qb, cnt = single.get_tables()
+    for r in ranks:
+        assert np.array_equal(r["qa"], qa) and np.array_equal(r["qb"], qb) and np.array_equal(r["count"], cnt)
+        assert r["decisions"] == single.stats()["decisions"]
+    reals, ints = single.get_fields()
+    assert np.array_equal(np.concatenate([ranks[0]["ints"], ranks[1]["ints"]], axis=1), ints)
+    assert np.array_equal(np.concatenate([ranks[0]["reals"], ranks[1]["reals"]], axis=1), reals)
+    assert cnt.sum() > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus():
