@@ -1,6 +1,6 @@
 """Classify the VALU instructions of a kernel's loops by the issue cost measured in tools/micro/pk_variants.hip.
 
-usage: classify.py dql.s <mangled kernel name>
+usage: isa_classify.py dql.s <mangled kernel name>
 For every backward branch (a loop) in the kernel: instruction counts by class -- plain VGPR/literal operands, with an SGPR
 source operand, packed (v_pk_*), transcendental (rcp/sqrt/rsq/...), 64-bit / f64, DPP, and non-VALU (SALU, memory, waitcnt).
 """
