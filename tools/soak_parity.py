@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off randomized parity soak: HIP engine vs CPU oracle over random points of the feature matrix (dtype, level, quirk
-set, axes, trajectory, per-env platform, observation noise, fold semantics, windowed exchange, block size), every field and
+set, axes, trajectory, per-env platform, observation noise, fold semantics, windowed exchange, block size, tick layout, periods per
+launch), every field and
 table compared bit for bit after every chunk.  The regular suite pins chosen points; this sweeps the space once.
 
     python tools/soak_parity.py [N_CONFIGS=24] [SEED=0]
@@ -27,9 +28,12 @@ for k in range(n_cfg):
     n = int(rng.choice([1, 63, 64, 65, 200, 512, 700]))
     seed = int(rng.integers(0, 2**31))
     windowed = rng.random() < 0.3
-    block = int(rng.choice([0, 0, 64, 256]))
+    block = int(rng.choice([0, 0, 64, 128, 256, 512])) if kw["dtype"] == F32 else int(rng.choice([0, 0, 64, 128, 256]))
+    tick = int(rng.integers(0, 5)) if kw["dtype"] == F32 else int(rng.integers(0, 4))   # 4 = literal constants: float32 + reference vehicle (the default config)
+    ppl = int(rng.choice([1, 1, 2, 3, 4]))
     eng = Engine(DqlConfig(**kw), n, seed=seed); orc = Oracle(DqlConfig(**kw), n, seed=seed, n_threads=8)
-    eng.set_option("block", block)
+    eng.set_option("block", block); eng.set_option("tick", tick)
+    eng.set_option("periods_per_launch", ppl); orc.set_option("periods_per_launch", ppl)
     if windowed:
         eng.set_windowed(True); orc.set_windowed(True)
     ok = True
@@ -57,7 +61,7 @@ for k in range(n_cfg):
     se, so = eng.stats(), orc.stats_dict()
     ok = ok and se["decisions"] == so["decisions"] and list(se["by_code"].values()) == so["by_code"] and se["reward_sum"] == so["reward_sum"]
     bad += not ok
-    print(json.dumps({"config": k, "ok": bool(ok), "n": n, "seed": seed, "windowed": bool(windowed), "block": block, "episodes": se["episodes"], **{a: (float(b) if isinstance(b, float) else int(b)) for a, b in kw.items()}}), flush=True)
+    print(json.dumps({"config": k, "ok": bool(ok), "n": n, "seed": seed, "windowed": bool(windowed), "block": block, "tick": tick, "periods_per_launch": ppl, "episodes": se["episodes"], **{a: (float(b) if isinstance(b, float) else int(b)) for a, b in kw.items()}}), flush=True)
     eng.close()
 print(json.dumps({"configs": n_cfg, "mismatching": bad}))
 sys.exit(1 if bad else 0)
