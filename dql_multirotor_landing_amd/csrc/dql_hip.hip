@@ -1,7 +1,7 @@
 // dql_hip.hip — kernels + C ABI (include/dql.h) of the MI355X UAV-landing / tabular Double-Q hot path.
 //
 // Kernels (all wave64, gfx950):
-//   k_step<T,BLOCK>          fused agent period: eps-greedy guess, 21/22 physics ticks (PID, SO(3) attitude law, rotor
+//   k_step<T,BLOCK,TICK>     fused agent period: eps-greedy guess, 21/22 physics ticks (PID, SO(3) attitude law, rotor
 //                            model, rigid body, platform, 100 Hz observation pipeline), discretise/check/reward, TD target.
 //                            One lane per env, state in VGPRs, 16-byte coalesced quad loads/stores, per-workgroup LDS
 //                            accumulators (int64 fixed-point target sums + visit counts), wave64 shuffle reductions of the
@@ -224,13 +224,12 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
                  "s_load_dword %4, %5, 0x300\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) : "s"(p));
 }
-// LONE: the register-hungry layout (per-tick constants in VGPRs, tick loop laid out per manager period: dql_device.hpp,
-// agent_period) for batches of at most a couple of waves per SIMD.  Every instantiation is capped at 2 waves per SIMD: measured
-// at 1 M envs, 3 resident waves are 7 % slower than 2 (and 4 no better), so the allocator may as well keep its registers.
+// TICK: layout of the 500 Hz loop (dql_device.hpp, agent_period: TICK_PLAIN / TICK_LONE / TICK_PACKED / TICK_LIT; launch_step_b
+// chooses).  Resident waves per SIMD by workgroup size:
 // 64 .. 256 threads: at most 2 waves per SIMD (68 KB of LDS accumulators per workgroup, or the register-hungry layouts); 512 threads:
 // two workgroups per CU = 4 waves per SIMD, so the compiler must stay within 128 VGPRs (it parks ~35 cold values in scratch)
 constexpr int step_waves_per_simd(int block) { return block == 512 ? 4 : 2; }
-template <typename T, int BLOCK, int LONE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
+template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
@@ -287,7 +286,7 @@ template <typename T, int BLOCK, int LONE> __global__ __launch_bounds__(BLOCK) _
       // a fresh or reset env has no previous state (idx -1): its row is never used, but the address must stay inside the table
       const QRow qx = load_qrow(a.qa, a.qb, (unsigned)e.idx_x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? e.idx_x : 0);
       const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-      const StepOut o = agent_period<LONE>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
+      const StepOut o = agent_period<TICK>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
         if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
@@ -574,10 +573,10 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
   return a;
 }
-template <typename T, int BLOCK, int LONE> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
+template <typename T, int BLOCK, int TICK> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
   const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK, n_periods);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((k_step<T, BLOCK, LONE>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
+  hipLaunchKernelGGL((k_step<T, BLOCK, TICK>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
 }
 // Which k_step variant serves a launch (options "block" and "tick"; 0 = auto).  Measured on MI355X, periods_per_launch 4
 // (profiles/r2_sweep_tick.jsonl, r2_sweep_occupancy.jsonl):
