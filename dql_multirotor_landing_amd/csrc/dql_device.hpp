@@ -790,6 +790,7 @@ struct StepOut {  // what one env contributes to the shared tables / counters th
   long long reward_fx;
   int cell, cell_y;     // table * N_CELLS + idx*3+action (table 0 = Q_table_a, 1 = Q_table_b), or -1
   int decision, done;
+  QRow next;            // acting-table row of the state the period ended in: the bootstrap's operand here, the next period's greedy row
 };
 
 struct PeriodCtx {
@@ -876,6 +877,9 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
     e.idx_y = idy;
   }
   e.reward = T(0.0);
+  // both tables' row of the new state, requested as soon as the index exists: check / reward below run while it travels, the TD target
+  // takes it from registers, and so does the NEXT period's greedy choice when the env stays in registers (periods_per_launch > 1)
+  out.next = load_qrow(qa, qb, idx);
   if (c.is_reset) return out;
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
   e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
@@ -894,10 +898,10 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
     const bool dbl = !(s.quirks & DQL_Q_UPDATE_TABLE_A_ONLY);
     {
       const bool sel_b = dbl && c.coin;
-      const double a0 = qa[idx * 3], a1 = qa[idx * 3 + 1], a2 = qa[idx * 3 + 2];
+      const double a0 = out.next.a0, a1 = out.next.a1, a2 = out.next.a2;
       double s0 = a0, s1 = a1, s2 = a2, v0 = a0, v1 = a1, v2 = a2;
       if (dbl) {
-        const double b0 = qb[idx * 3], b1 = qb[idx * 3 + 1], b2 = qb[idx * 3 + 2];
+        const double b0 = out.next.b0, b1 = out.next.b1, b2 = out.next.b2;
         s0 = sel_b ? b0 : a0; s1 = sel_b ? b1 : a1; s2 = sel_b ? b2 : a2;
         v0 = sel_b ? a0 : b0; v1 = sel_b ? a1 : b1; v2 = sel_b ? a2 : b2;
       }

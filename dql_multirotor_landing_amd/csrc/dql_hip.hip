@@ -272,10 +272,13 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   // round trip through HBM, the launch boundary and the table-writer work are paid once per P periods; the acting tables are
   // those of the launch for all P periods, every period's TD targets go to the launch's accumulators
   Env<T> e;
+  QRow qx = QRow{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < a.n) {
     // the packed ints go first: their state index addresses the acting-table row, whose request then rides along with the
-    // state quads instead of waiting for them (one memory round trip less at the head of the wave)
+    // state quads instead of waiting for them (one memory round trip less at the head of the wave).  A fresh or reset env has
+    // no previous state (idx -1): its row is never used, but the address must stay inside the table
     const int4 iv = a.si[i];
+    qx = load_qrow(a.qa, a.qb, (unsigned)iv.x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? iv.x : 0);
     load_env(e, a.sr, iv, a.n, i, a.c);
     DQL_MARK_T(e, 2);
   }
@@ -283,8 +286,6 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   for (int p = 0; p < a.n_periods; ++p) {
     dec = 0; don = 0; rfx = 0; goal = false;
     if (i < a.n) {
-      // a fresh or reset env has no previous state (idx -1): its row is never used, but the address must stay inside the table
-      const QRow qx = load_qrow(a.qa, a.qb, (unsigned)e.idx_x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? e.idx_x : 0);
       const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
       const StepOut o = agent_period<TICK>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
       if (STAGED) {
@@ -295,6 +296,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
         if (o.cell >= 0) { const int g = o.cell + (o.cell >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
         if (o.cell_y >= 0) { const int g = o.cell_y + (o.cell_y >= DQL_N_CELLS ? DQL_N_CELLS : 0); atomicAdd(&a.acc_cur[g], (unsigned long long)o.target_y_fx); atomicAdd(&a.acc_cur[DQL_N_CELLS + g], 1ull); }
       }
+      qx = o.next;  // the row of the state this period ended in = the next period's greedy row (the launch's tables act for all P)
       dec = o.decision; don = o.done; rfx = o.reward_fx;
       if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
     }
