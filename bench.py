@@ -384,8 +384,8 @@ def valu_roofline(args, k_ms):
     out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
            "source": f"profiles/{pf.name} (instruction count), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
     # own mix per tick (tools/isa_sections.py x the table above): plain loop 250 full-rate + 28 four-cycle + 88 SGPR-operand + 4 sqrt of 370
-    # = 1.39 ns; literal-constant loop (>= 262 144 envs) 304 + 33 + 18 + 4 of 359 = 1.27 ns; packed lone wave 2.3 ns
-    mix = 2.3 if lone else (1.27 if args.envs >= 262144 else 1.39)
+    # = 1.39 ns; literal-constant loop (> 196 608 envs) 304 + 33 + 18 + 4 of 359 = 1.27 ns; packed lone wave 2.3 ns
+    mix = 2.3 if lone else (1.27 if args.envs > 196608 else 1.39)
     prices = (("all_full_rate", 2.2 if lone else 1.15), ("own_mix", mix), ("guide_table", (4 if lone else 2) / 2.4))
     for tag, ns in prices:
         floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)

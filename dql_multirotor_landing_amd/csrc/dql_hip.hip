@@ -582,8 +582,9 @@ template <typename T, int BLOCK, int TICK> static void launch_step_t(dql_ctx* x,
 }
 // Which k_step variant serves a launch (options "block" and "tick"; 0 = auto).  Measured on MI355X, periods_per_launch 4
 // (profiles/r2_sweep_tick.jsonl, r2_sweep_occupancy.jsonl):
-//   block  64 (no LDS staging, one wave per workgroup) up to 8 192 envs; 256 (2 waves per SIMD) up to 131 072; 512 with the register
-//          budget of 4 waves per SIMD from 262 144 envs (float32: -3 % plain, -6 % with literal constants at 1 M envs)
+//   block  64 (no LDS staging, one wave per workgroup) up to 8 192 envs; 256 (2 waves per SIMD) up to 196 608; 512 with the register
+//          budget of 4 waves per SIMD beyond (float32: -3 % plain, -6 % with literal constants at 1 M envs; 229 376 envs: 59.6 vs
+//          63.3 us, 196 608: 57.0 vs 52.8)
 //   tick   packed float32 tick while a SIMD hosts at most one env wave (<= 65 536 envs: 18.7 vs 20.2 us at 4 096, 20.8 vs 22.3 at
 //          32 768; beside a second wave a packed instruction costs two issue slots and the layout LOSES: 45 vs 36 us at 131 072);
 //          literal constants with the 512-thread block when the vehicle is the reference's; the plain loop otherwise.
@@ -597,7 +598,7 @@ template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps
     else if (block == 128) launch_step_t<T, 128, TICK_PLAIN>(x, mode, eps, np);
     else launch_step_t<T, 256, TICK_PLAIN>(x, mode, eps, np);
   } else {
-    if (block == 0) block = (x->n <= 8192) ? 64 : (x->n < 262144 || tick == 2 || tick == 3 ? 256 : 512);
+    if (block == 0) block = (x->n <= 8192) ? 64 : (x->n <= 196608 || tick == 2 || tick == 3 ? 256 : 512);
     if (tick == 0) tick = x->n <= 65536 ? 3 : (block == 512 && x->lit_ok ? 4 : 1);
     if (tick == 4 && !x->lit_ok) tick = 1;
     if (block == 128 || (block == 512 && tick != 4)) tick = 1;
