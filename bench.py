@@ -118,10 +118,10 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
 # (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
 # B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl); 4 judged envs:
 # the deque sees the episodes of 4 envs (1 = the reference's own situation is the Trainer's default: same policy quality, a level
-# that sits at 93-95 % online success then needs ~2x the episodes until a 97 / 100 window comes by); 4 agent periods per launch,
-# table exchange every 4
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 4}
-CURRICULUM_SYNC = 4
+# that sits at 93-95 % online success then needs ~2x the episodes until a 97 / 100 window comes by); 8 agent periods per launch
+# and table exchange every 8 (measured against 4 / 4: same policy quality, more levels promoted, profiles/r2_curriculum_p8.jsonl)
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 8}
+CURRICULUM_SYNC = 8
 
 
 def spawn_ranks(args) -> int:
@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1.0)
     ap.add_argument("--sync-period", type=int, default=32, help="agent periods between table exchanges of the headline run (N > 1); sync_period 2 is reported next to it")
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--periods-per-launch", type=int, default=4, help="agent periods per kernel launch (engine option; 1 = one launch per period)")
+    ap.add_argument("--periods-per-launch", type=int, default=8, help="agent periods per kernel launch (engine option; 1 = one launch per period)")
     ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
@@ -227,10 +227,11 @@ def main():
                     noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
-    eng.set_option("periods_per_launch", args.periods_per_launch)
-    if args.steps % args.periods_per_launch or args.sync_period % args.periods_per_launch:
-        print("bench.py: --steps and --sync-period must be multiples of --periods-per-launch", file=sys.stderr)
+    # any --steps K works: the engine cuts K periods into launches of at most P (the last one shorter)
+    if not 1 <= args.periods_per_launch <= 8:
+        print("bench.py: --periods-per-launch must be in 1..8", file=sys.stderr)
         sys.exit(2)
+    eng.set_option("periods_per_launch", args.periods_per_launch)
     reducer = RcclWindowReducer(eng, comm) if world > 1 else None
 
     def barrier():
@@ -250,9 +251,9 @@ def main():
         t0 = time.perf_counter()
         runner.train_steps(steps, args.eps)
         runner.sync()
-        dev_ms = eng.timer_stop()
+        dev_ms = eng.timer_stop()          # waits for the stream: this rank's K steps are done
+        wall = time.perf_counter() - t0    # (MAX over ranks below = the job's time)
         barrier()
-        wall = time.perf_counter() - t0
         s1 = eng.stats()
         dec = s1["decisions"] - s0["decisions"]
         if comm:
@@ -288,7 +289,10 @@ def main():
     eng.kernel_timer(False)
     s2 = eng.stats()
     dec_per_launch = P * (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])  # one launch = P agent periods
-    k_ms = dev_ms / (args.steps // P) if world == 1 else k_pairs_ms
+    n_launch = -(-args.steps // P)  # ceil: the last launch of the timed region may hold fewer than P periods
+    k_ms = dev_ms / n_launch if world == 1 else k_pairs_ms
+    if world == 1:
+        dec_per_launch = decisions / n_launch  # average over the launches of the timed region (kernel_avg_ms is their average duration)
 
     curriculum = None
     if not args.no_curriculum and not args.two_axis:
@@ -318,7 +322,7 @@ def main():
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": args.steps // P if world == 1 else k_n, "agent_periods_per_launch": P,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch if world == 1 else k_n, "agent_periods_per_launch": P,
                          "kernel_avg_ms_event_pairs": k_pairs_ms,
                          "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
@@ -375,7 +379,10 @@ def valu_roofline(args, k_ms):
         return None
     pm = json.loads(pf.read_text())
     P = args.periods_per_launch
-    ref = pm.get(f"{args.envs}_p{P}") or pm.get(f"{1048576 if args.envs > 262144 else 4096}_p{P}")
+    # instruction count per env wave per PERIOD: the pass of this env count (any periods per launch; the count per period moves by
+    # < 2 % with it), else the nearest committed size
+    cands = sorted(pm, key=lambda k: (abs(int(k.split("_p")[0]) - args.envs), abs(int(k.split("_p")[1]) - P)))
+    ref = pm[cands[0]] if cands else None
     if not ref:
         return None
     valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * P  # per launch

@@ -167,7 +167,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
   return q;
 }
 
-#define DQL_MAX_PERIODS 4  // agent periods one launch may run back to back per env (option "periods_per_launch")
+#define DQL_MAX_PERIODS 8  // agent periods one launch may run back to back per env (option "periods_per_launch")
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T>* mdp;
@@ -216,13 +216,19 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
                : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(p));
   // the remaining lines, only those the arguments reach; loads and their wait stay inside ONE asm statement (the compiler must
   // not reuse a destination register while a load into it is still in flight)
-  static_assert((BYTES > 0x200 && BYTES <= 0x240) || (BYTES > 0x300 && BYTES <= 0x340), "adjust the touch list to the argument size");
+  static_assert(BYTES > 0x200 && BYTES <= 0x380 && !(BYTES > 0x280 && BYTES <= 0x300), "adjust the touch list to the argument size");
   if constexpr (BYTES <= 0x240)
     asm volatile("s_load_dword %0, %1, 0x200\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0) : "s"(p));
-  else
+  else if constexpr (BYTES <= 0x280)
+    asm volatile("s_load_dword %0, %2, 0x200\n\ts_load_dword %1, %2, 0x240\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1) : "s"(p));
+  else if constexpr (BYTES <= 0x340)
     asm volatile("s_load_dword %0, %5, 0x200\n\ts_load_dword %1, %5, 0x240\n\ts_load_dword %2, %5, 0x280\n\ts_load_dword %3, %5, 0x2c0\n\t"
                  "s_load_dword %4, %5, 0x300\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) : "s"(p));
+  else
+    asm volatile("s_load_dword %0, %6, 0x200\n\ts_load_dword %1, %6, 0x240\n\ts_load_dword %2, %6, 0x280\n\ts_load_dword %3, %6, 0x2c0\n\t"
+                 "s_load_dword %4, %6, 0x300\n\ts_load_dword %5, %6, 0x340\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(p));
 }
 // TICK: layout of the 500 Hz loop (dql_device.hpp, agent_period: TICK_PLAIN / TICK_LONE / TICK_PACKED / TICK_LIT; launch_step_b
 // chooses).  Resident waves per SIMD by workgroup size:
@@ -810,7 +816,16 @@ int dql_destroy(dql_ctx* x) {
   return DQL_OK;
 }
 
-int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipStreamSynchronize(x->stream)); return DQL_OK; }
+// Host wait for the context's stream: poll first (a blocking hipStreamSynchronize parks the thread and wakes it 20-40 us after the
+// GPU is done, which is most of a short run), block only when the work is long
+static hipError_t wait_stream(hipStream_t st) {
+  for (int i = 0; i < 20000; ++i) {  // ~ a few ms of polling at most
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+  }
+  return hipStreamSynchronize(st);
+}
+int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipSetDevice(x->device)); HIP_TRY(wait_stream(x->stream)); return DQL_OK; }
 int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); if (!n) return fail(DQL_EINVAL, "null pointer"); *n = x->n; return DQL_OK; }
 int dql_state_bytes_per_env(dql_ctx* x, int64_t* bytes) {
   CHECK_CTX(x);
@@ -1168,7 +1183,7 @@ int dql_timer_stop(dql_ctx* x, double* ms) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipEventRecord(x->ev1, x->stream));
-  HIP_TRY(hipEventSynchronize(x->ev1));
+  HIP_TRY(wait_stream(x->stream));
   float f = 0;
   HIP_TRY(hipEventElapsedTime(&f, x->ev0, x->ev1));
   if (ms) *ms = (double)f;
@@ -1215,7 +1230,7 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");
   if (!strcmp(name, "periods_per_launch")) {
-    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..4");
+    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..8");
     x->periods_per_launch = value;
     return DQL_OK;
   }

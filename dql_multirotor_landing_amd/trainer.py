@@ -131,8 +131,8 @@ class Trainer:
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
         self._checkpoint_env_state = bool(checkpoint_env_state)
         self._periods_per_launch = int(periods_per_launch)
-        if not 1 <= self._periods_per_launch <= 4 or self._chunk_steps % self._periods_per_launch:
-            raise ValueError("periods_per_launch must be in 1..4 and divide chunk_steps")
+        if not 1 <= self._periods_per_launch <= 8 or self._chunk_steps % self._periods_per_launch:
+            raise ValueError("periods_per_launch must be in 1..8 and divide chunk_steps")
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
         self._reducer_factory = reducer_factory
         self._rank = self._comm.rank if self._comm else 0

@@ -8,6 +8,7 @@ mkdir -p $O
 cd $R
 if [ $WHAT != pmc ]; then
 python bench.py > $O/bench_4096.json 2> $O/bench_4096.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_4096_driver_args.json 2>> $O/bench_4096.err
 echo bench done
 python bench.py --envs 32768 --no-curriculum --no-cpu-baseline --large-envs 0 > $O/bench_32768.json 2>> $O/bench.err
 python bench.py --envs 131072 --randomize-platform 1 --noise 1 --steps 1000 --warmup 100 --no-curriculum --no-cpu-baseline --large-envs 0 > $O/bench_config5_131072.json 2>> $O/bench.err
@@ -19,11 +20,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 echo stats done
 fi
 if [ $WHAT != bench ]; then
-for cfg in "4096 200" "32768 200" "131072 120" "1048576 60"; do
+for cfg in "4096 400" "32768 400" "131072 240" "1048576 120"; do
   set -- $cfg
-  rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES -d $O/pmc_sq_$1_p4 -- python3 $R/tools/prof_run.py $1 $2 0 4 > /dev/null 2>> $O/pmc.err
-  rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch_$1_p4 -- python3 $R/tools/prof_run.py $1 $2 0 4 > /dev/null 2>> $O/pmc.err
-  rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write_$1_p4 -- python3 $R/tools/prof_run.py $1 $2 0 4 > /dev/null 2>> $O/pmc.err
+  rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES -d $O/pmc_sq_$1_p8 -- python3 $R/tools/prof_run.py $1 $2 0 8 > /dev/null 2>> $O/pmc.err
+  rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch_$1_p8 -- python3 $R/tools/prof_run.py $1 $2 0 8 > /dev/null 2>> $O/pmc.err
+  rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write_$1_p8 -- python3 $R/tools/prof_run.py $1 $2 0 8 > /dev/null 2>> $O/pmc.err
   echo pmc $1 done
 done
 fi
