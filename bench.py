@@ -331,7 +331,7 @@ def main():
         if sync_info:
             out["sync"] = sync_info
             out["sync_ms_per_step"] = sync_info["sync_ms_per_step"]
-        valu = valu_roofline(args, k_ms)
+        valu = valu_roofline(args, k_ms, args.steps / n_launch if world == 1 else P)
         if valu:
             out["valu_roofline"] = valu
         if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
@@ -360,7 +360,7 @@ def main():
         comm.close()
 
 
-def valu_roofline(args, k_ms):
+def valu_roofline(args, k_ms, periods_per_launch_avg):
     """The roof that actually binds: wave64 VALU instructions through 1024 SIMDs, with the instruction count per env wave from the
     committed PMC pass (profiles/r2_pmc_sq_summary.json) and issue costs per instruction FORM from the asm micro benchmarks
     (tools/micro/pk_variants.hip, valu_forms.hip -> profiles/r2_pk_variants.jsonl, r2_valu_forms.jsonl; placement verified from HW_ID).
@@ -385,7 +385,7 @@ def valu_roofline(args, k_ms):
     ref = pm[cands[0]] if cands else None
     if not ref:
         return None
-    valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * P  # per launch
+    valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * periods_per_launch_avg  # per (average) launch of the timed region
     waves = (args.envs + 63) // 64
     lone = waves <= 1024
     out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
