@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-rehearsal", action="store_true",
+                    help="one rank, but through every code path of a multi-rank run (RCCL communicator of world size 1, window exchange, sync legs, sharded curriculum): a rehearsal on a 1-GPU box, flagged in the line, not a measurement")
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
@@ -216,6 +218,10 @@ def main():
     dtype = F32 if args.dtype == "f32" else F64
     dev_index = local_rank
     comm = None
+    multi = world > 1 or args.exchange_rehearsal  # the exchange path (always with several ranks)
+    if args.exchange_rehearsal and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        comm = RcclComm(0, 1, dev_index)
     if world > 1:
         try:
             comm = RcclComm.from_env(dev_index)  # one GPU per rank or an error: never a silent 1-GPU measurement
@@ -223,7 +229,9 @@ def main():
             print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
             sys.exit(3)
 
-    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis, per_env_platform=args.randomize_platform,
+    # fold_per_step = 1: the Trainer's default table update (one learning-rate step per agent period towards the period's mean
+    # target) — the throughput leg runs the update rule the curriculum leg trains with
+    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis, per_env_platform=args.randomize_platform, fold_per_step=1,
                     noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
@@ -232,7 +240,7 @@ def main():
         print("bench.py: --periods-per-launch must be in 1..8", file=sys.stderr)
         sys.exit(2)
     eng.set_option("periods_per_launch", args.periods_per_launch)
-    reducer = RcclWindowReducer(eng, comm) if world > 1 else None
+    reducer = RcclWindowReducer(eng, comm) if multi else None
 
     def barrier():
         eng.sync()
@@ -266,7 +274,7 @@ def main():
 
     wall, decisions, dev_ms = timed(args.sync_period, args.steps, args.warmup)
     sync_info = None
-    if world > 1:
+    if multi:
         # the exchange's price: same region without exchanges (one window, folded after the clock stops: NOT a valid training
         # schedule, a yardstick), and at sync_period 2 (the regime in which the run does not depend on the number of ranks)
         w_none, d_none, _ = timed(args.steps + args.warmup + 1, args.steps, 0, final_exchange=False)
@@ -294,8 +302,8 @@ def main():
     s2 = eng.stats()
     dec_per_launch = P * (s2["decisions"] - s1["decisions"]) / max(1, s2["agent_steps"] - s1["agent_steps"])  # one launch = P agent periods
     n_launch = -(-args.steps // P)  # ceil: the last launch of the timed region may hold fewer than P periods
-    k_ms = dev_ms / n_launch if world == 1 else k_pairs_ms
-    if world == 1:
+    k_ms = dev_ms / n_launch if not multi else k_pairs_ms
+    if not multi:
         dec_per_launch = decisions / n_launch  # average over the launches of the timed region (kernel_avg_ms is their average duration)
 
     curriculum = None
@@ -320,13 +328,13 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
                                    f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per {args.periods_per_launch} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
-                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if world > 1 else 1,
-                       "periods_per_launch": args.periods_per_launch,
-                       "parallelism": f"env-shard x{world}" + (", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)" if world > 1 else ""), "block": args.block,
+                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if multi else 1, "exchange_rehearsal": bool(args.exchange_rehearsal),
+                       "periods_per_launch": args.periods_per_launch, "fold_per_step": 1,
+                       "parallelism": f"env-shard x{world}" + (", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)" if multi else ""), "block": args.block,
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch if world == 1 else k_n, "agent_periods_per_launch": P,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch if not multi else k_n, "agent_periods_per_launch": P,
                          "kernel_avg_ms_event_pairs": k_pairs_ms,
                          "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
                          "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
@@ -335,12 +343,12 @@ def main():
         if sync_info:
             out["sync"] = sync_info
             out["sync_ms_per_step"] = sync_info["sync_ms_per_step"]
-        valu = valu_roofline(args, k_ms, args.steps / n_launch if world == 1 else P)
+        valu = valu_roofline(args, k_ms, args.steps / n_launch if not multi else P)
         if valu:
             out["valu_roofline"] = valu
-        if world == 1 and args.envs != args.large_envs and args.large_envs > 0:
+        if not multi and args.envs != args.large_envs and args.large_envs > 0:
             # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
-            big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis), args.large_envs, seed=42)
+            big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis, fold_per_step=1), args.large_envs, seed=42)
             big.set_option("periods_per_launch", P)
             big.train_steps(5 * P, args.eps); big.sync()
             b0 = big.stats(); big.timer_start(); big.train_steps(40 * P, args.eps); b_ms = big.timer_stop(); b1 = big.stats()
@@ -355,7 +363,7 @@ def main():
                 out["goal_hold_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["goal_hold_rate"]
                 out["touchdown_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["touchdown_rate"]
                 out["wall_to_stage4_s"] = curriculum["wall_to_stage4_s"]
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
         print(json.dumps(out), flush=True)
     eng.close()

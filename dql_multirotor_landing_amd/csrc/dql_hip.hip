@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed on first use (dql_comm_*)
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
@@ -139,7 +140,18 @@ DQL_DEV double fold_q(const FoldK& f, double q, double cnt, long long Tsum, long
   // per_step: one learning-rate step per launch the accumulators cover (1 for a launch's own fold, the window length for
   // the multi-GPU window), never more steps than visits
   const long long m_eff = f.per_step ? (m < f.n_launch ? m : f.n_launch) : m;
-  for (; j < m_eff && c0 + j < f.n_tab; ++j) shrink *= (1.0 - f.alpha_tab[c0 + j]);
+  // the learning rates of visits c0, c0+1, ... up to the table's plateau: loads in batches of 8 (independent, one memory round trip per
+  // batch), products in visit order — the same sequence of multiplications as a plain loop, 8x fewer round trips (a fresh table
+  // folds hundreds of visits per cell: 160 us per fold kernel before, profiles/r2_exchange_kernels.csv)
+  const long long jn = (m_eff < f.n_tab - c0) ? m_eff : (f.n_tab - c0 > 0 ? f.n_tab - c0 : 0);
+  for (; j + 8 <= jn; j += 8) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = f.alpha_tab[c0 + j + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) shrink *= (1.0 - a[k]);
+  }
+  for (; j < jn; ++j) shrink *= (1.0 - f.alpha_tab[c0 + j]);
   long long rem = m_eff - j;
   if (rem > 0) {
     double base = 1.0 - f.alpha_min, pw = 1.0;
@@ -1509,7 +1521,15 @@ int dql_comm_create(int device, int32_t rank, int32_t world, const uint8_t* id, 
   int rc = DQL_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(DQL_EHIP, "hipStreamCreate failed"); break; }
+    // RCCL 2.27 prints a version banner on STDOUT from ncclCommInitRank (no switch for it): a launcher that reads one result line
+    // from rank 0's stdout must not find it there.  Park fd 1 on stderr for the duration of the call (one host thread per
+    // process talks to this library while a communicator is created).
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) (void)dup2(2, 1);
     const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+    fflush(stdout);
+    if (saved_out >= 0) { (void)dup2(saved_out, 1); (void)close(saved_out); }
     if (r != ncclSuccess) { c->nccl = nullptr; rc = fail(DQL_ERCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); break; }
   } while (0);
   if (rc) { const std::string why = g_err; dql_comm_destroy(c); return fail(rc, why); }
