@@ -880,6 +880,7 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
   // both tables' row of the new state, requested as soon as the index exists: check / reward below run while it travels, the TD target
   // takes it from registers, and so does the NEXT period's greedy choice when the env stays in registers (periods_per_launch > 1)
   out.next = load_qrow(qa, qb, idx);
+  DQL_MARK_T(e, 41);
   if (c.is_reset) return out;
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
   e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
@@ -887,6 +888,7 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env
   T rew_y = T(0.0);
   if (two) rew_y = mdp_reward(m, e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y, e.code, idy, e.obs_py, e.obs_vy, -e.roll_sp);
   e.reward = two ? rew + rew_y : rew;
+  DQL_MARK_T(e, 42);
   const bool done = e.code <= DQL_TERMINAL_TIMEOUT;
   if (done) e.flags |= FL_DONE;
   out.decision = 1; out.done = done ? 1 : 0;
@@ -951,14 +953,23 @@ template <int TICK, typename T> struct TickK { static DQL_DEV const SimK<T>& get
 template <> struct TickK<TICK_LONE, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
 template <> struct TickK<TICK_PACKED, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
 template <> struct TickK<TICK_LIT, float> { static DQL_DEV LitK get(const SimK<float>& s) { return LitK{s.vz_sp, s.yw_sp}; } };
+// The tick constants in the form the layout wants them (SGPR struct, VGPR copies, literals) + the packed pairs: made ONCE per launch,
+// outside the loop over the launch's agent periods
+template <int TICK, typename T> struct TickConsts {
+  decltype(TickK<TICK, T>::get(*(const SimK<T>*)nullptr)) h;
+  PkK pk;
+  DQL_DEV explicit TickConsts(const SimK<T>& s) : h(TickK<TICK, T>::get(s)) {
+    if constexpr (sizeof(T) == 4 && TICK == TICK_PACKED) pk = make_pkk(h);
+  }
+};
 template <int TICK, typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
+DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T>* __restrict__ mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
                              int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
   T B[9];
   make_B(e.pitch_sp, e.roll_sp, B);
   constexpr bool HOT = TICK == TICK_LONE || TICK == TICK_PACKED;
-  const auto h = TickK<TICK, T>::get(s);
+  const auto& h = tc.h;
   DQL_MARK_T(e, 3);
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
@@ -987,7 +998,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const MdpK<T>* __restrict__ mp, E
     // float32: the packed tick (physics_tick_pk): the state the 500 Hz loop touches lives in register pairs for the whole period
     TickPk ts;
     pack_tick(e, ts);
-    const PkK pk = make_pkk(h);
+    const PkK& pk = tc.pk;
     const f2 B01 = f2{B[0], B[1]}, B34 = f2{B[3], B[4]}, B67 = f2{B[6], B[7]};
     const float B2 = B[2], B5 = B[5], B8 = B[8];
     RotPk rp;

@@ -301,11 +301,12 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     DQL_MARK_T(e, 2);
   }
   long long dec_w = 0, don_w = 0, rfx_w = 0;  // per-wave totals over the periods of this launch (wave-uniform after the reductions)
+  const TickConsts<TICK, T> tc(a.c);
   for (int p = 0; p < a.n_periods; ++p) {
     dec = 0; don = 0; rfx = 0; goal = false;
     if (i < a.n) {
       const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
-      const StepOut o = agent_period<TICK>(a.c, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
+      const StepOut o = agent_period<TICK>(a.c, tc, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
         if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }

@@ -5,7 +5,8 @@
     for k in 2 3 4 5 6 7; do tools/ab_build.sh clock$k -DDQL_WAVE_CLOCK=$k; done
     DQL_LIB_PATH=$PWD/dql_multirotor_landing_amd/csrc/libdql_hip_clock7.so python tools/exp_wave_clock.py
 Phase k ends when: 2 state loaded, 3 action chosen + set-point matrix (Q-table reads), 4 tick loop done, 5 MDP + TD target done,
-6 state stored + LDS accumulation issued, 7 wave end (all memory operations complete).
+6 state stored + LDS accumulation issued, 7 wave end (all memory operations complete); inside phase 5: 41 new state index known (rotation,
+Euler pitch, discretise; table row requested), 42 check + reward done (lanes that did not reset).
 """
 import json, sys, time
 from pathlib import Path
