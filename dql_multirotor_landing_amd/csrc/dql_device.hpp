@@ -588,7 +588,11 @@ template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<
 // B = Rx(roll_sp) Ry(pitch_sp) (attitude_controller.py:138-140), constant over one agent period
 template <typename T> DQL_DEV void make_B(T pitch_sp, T roll_sp, T (&B)[9]) {
   T sp_, cp_, sr_, cr_;
-  det_sincos(pitch_sp, sp_, cp_); det_sincos(roll_sp, sr_, cr_);
+  det_sincos(pitch_sp, sp_, cp_);
+  // x-axis configs fly with a roll set-point of exactly 0 in every lane: det_sincos(+-0) is (+0, 1) bit for bit (fn = +-0, r = +0,
+  // sin_k(+0) = +0, cos_k(+0) = 1), so the whole wave skips the second evaluation; two-axis lanes with roll != 0 take it as before
+  if (roll_sp == T(0.0)) { sr_ = T(0.0); cr_ = T(1.0); }
+  else det_sincos(roll_sp, sr_, cr_);
   B[0] = cp_; B[1] = T(0.0); B[2] = sp_;
   B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_);
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
