@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 echo stats done
 fi
 if [ $WHAT != bench ]; then
+rm -rf $O/pmc_*
 for cfg in "4096 400" "32768 400" "131072 240" "1048576 120"; do
   set -- $cfg
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES -d $O/pmc_sq_$1_p8 -- python3 $R/tools/prof_run.py $1 $2 0 8 > /dev/null 2>> $O/pmc.err

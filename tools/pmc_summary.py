@@ -15,7 +15,7 @@ sq, tr = {}, defaultdict(dict)
 for d in sys.argv[1:]:
     m = re.search(r"pmc_(sq|fetch|write)_(\d+)_p(\d+)$", d.rstrip("/"))
     kind, envs, P = m.group(1), int(m.group(2)), int(m.group(3))
-    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=lambda x: Path(x).stat().st_mtime)  # the newest pass in the directory
     per = defaultdict(list); kname = None
     for r in csv.DictReader(open(f)):
         if "k_step" in r["Kernel_Name"]:
