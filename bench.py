@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
     ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"],
+                    help="table exchange between ranks: RCCL all-reduce (default) or the one-shot peer-to-peer push + local sum (dql_p2p_*: opt-in, "
+                         "functionally tested with ranks sharing one GPU, not yet measured across GPUs)")
     ap.add_argument("--exchange-rehearsal", action="store_true",
                     help="one rank, but through every code path of a multi-rank run (RCCL communicator of world size 1, window exchange, sync legs, sharded curriculum): a rehearsal on a 1-GPU box, flagged in the line, not a measurement")
     ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
@@ -212,7 +215,7 @@ def main():
     g.build_hip()
     from dql_multirotor_landing_amd.comm import RcclComm
     from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
-    from dql_multirotor_landing_amd.dist import RcclWindowReducer, ShardedRunner
+    from dql_multirotor_landing_amd.dist import P2PWindowReducer, RcclWindowReducer, ShardedRunner
     from dql_multirotor_landing_amd.engine import Engine
 
     dtype = F32 if args.dtype == "f32" else F64
@@ -240,7 +243,9 @@ def main():
         print("bench.py: --periods-per-launch must be in 1..8", file=sys.stderr)
         sys.exit(2)
     eng.set_option("periods_per_launch", args.periods_per_launch)
-    reducer = RcclWindowReducer(eng, comm) if multi else None
+    reducer = None
+    if multi:
+        reducer = P2PWindowReducer(eng, rank, world) if args.exchange == "p2p" else RcclWindowReducer(eng, comm)
 
     def barrier():
         eng.sync()
@@ -285,7 +290,9 @@ def main():
         eng.kernel_timer(False)
         sync_info = {"sync_period": args.sync_period, "ms_per_step": wall * 1e3 / args.steps, "ms_per_step_no_exchange": w_none * 1e3 / args.steps,
                      "sync_ms_per_step": (wall - w_none) * 1e3 / args.steps, "exchange_device_ms": sync_dev_ms, "exchanges_timed": n_sync,
-                     "exchange": "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream",
+                     "exchange": ("flush + push of 11 340 int64 words into every rank's exchange buffer (HIP IPC, uncached) + flags + local sum + fold, on the engine's stream"
+                                  if args.exchange == "p2p" else "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream"),
+                     "p2p_failed": eng.p2p_failed() if args.exchange == "p2p" else None,
                      "sync_period_2": {"value": d_two / w_two, "ms_per_step": w_two * 1e3 / args.steps, "sync_ms_per_step": (w_two - w_none) * 1e3 / args.steps}}
 
     # Average launch duration of the fused step kernel, HIP events on the engine's stream.  One rank: the step kernel is the
@@ -330,7 +337,7 @@ def main():
                                    f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per {args.periods_per_launch} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if multi else 1, "exchange_rehearsal": bool(args.exchange_rehearsal),
                        "periods_per_launch": args.periods_per_launch, "fold_per_step": 1,
-                       "parallelism": f"env-shard x{world}" + (", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)" if multi else ""), "block": args.block,
+                       "parallelism": f"env-shard x{world}" + ((", one-shot peer-to-peer window exchange (libdql_hip.so, HIP IPC)" if args.exchange == "p2p" else ", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)") if multi else ""), "block": args.block,
                        "randomize_platform": args.randomize_platform, "noise": args.noise},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,

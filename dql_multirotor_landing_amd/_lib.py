@@ -14,6 +14,8 @@ LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # overr
 OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL = 0, -1, -2, -3, -4, -5
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
+P2P_MAX_RANKS = 8
 OP_SUM, OP_MAX = 0, 1
 
 
@@ -78,6 +80,10 @@ SYMBOLS = {
     "dql_comm_barrier": (C.c_int, [_vp]),
     "dql_attach_comm": (C.c_int, [_vp, _vp]),
     "dql_allreduce_window": (C.c_int, [_vp]),
+    "dql_p2p_create": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "dql_p2p_connect": (C.c_int, [_vp, _vp]),
+    "dql_p2p_exchange_window": (C.c_int, [_vp]),
+    "dql_p2p_status": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "dql_sync_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
     "dql_stats_get": (C.c_int, [_vp, C.POINTER(DqlStatsC)]),
     "dql_stats_reset": (C.c_int, [_vp]),

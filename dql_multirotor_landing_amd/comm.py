@@ -48,6 +48,48 @@ def id_file_path(seq: int) -> Path:
     return Path(tempfile.gettempdir()) / f"dql_comm_{os.getuid()}_{_parent_token()}_{port}_{seq}.id"
 
 
+def gather_via_files(tag: str, rank: int, world: int, payload: bytes, timeout_s: float = 600.0):
+    """All-gather of one small byte string per rank through files every sibling rank can name (same naming scheme as the
+    communicator's unique id): for bootstrap data such as the HIP IPC handles of the peer-to-peer exchange, which must not depend
+    on a collective library.  Returns the payloads in rank order; every rank removes its own file once all are read."""
+    base = id_file_path(0)
+    mine = base.with_name(f"{base.stem}.{tag}.{rank}.bin")
+    tmp = mine.with_suffix(f".{os.getpid()}.tmp")
+    tmp.write_bytes(payload)
+    os.replace(tmp, mine)
+    out, t0 = [], time.monotonic()
+    for r in range(world):
+        f = base.with_name(f"{base.stem}.{tag}.{r}.bin")
+        while True:
+            try:
+                b = f.read_bytes()
+                if len(b) == len(payload):
+                    break
+            except OSError:
+                pass
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError(f"rank {rank}: nothing from rank {r} after {timeout_s:.0f} s ({f})")
+            time.sleep(0.01)
+        out.append(b)
+    # a second round of marker files: nobody deletes what a slower rank has not read yet
+    done = base.with_name(f"{base.stem}.{tag}.{rank}.done")
+    done.write_bytes(b"1")
+    for r in range(world):
+        d = base.with_name(f"{base.stem}.{tag}.{r}.done")
+        while not d.exists():
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError(f"rank {rank}: rank {r} never finished reading ({d})")
+            time.sleep(0.01)
+    if rank == 0:  # all ranks have read everything and written their marker: rank 0 clears the data files, each rank its own marker later
+        for r in range(world):
+            try:
+                base.with_name(f"{base.stem}.{tag}.{r}.bin").unlink()
+            except OSError:
+                pass
+    atexit.register(lambda: done.exists() and done.unlink())
+    return out
+
+
 class RcclComm:
     """A rank's RCCL communicator + the Trainer's control-plane exchanges (per-chunk counters: sum; bench timing: max;
     judged envs' episode logs: gather in rank order = global env order)."""

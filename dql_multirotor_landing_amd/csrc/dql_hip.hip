@@ -496,6 +496,51 @@ __global__ void k_update_seq(double* qa, double* qb, double* count, const int* s
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
+// ---- one-shot peer-to-peer exchange of the window accumulators (second step) ----
+// Exchange buffer of a rank: slots[2 parities][world][DQL_ACC_LEN] int64, then flags[2 parities][DQL_P2P_MAX_RANKS] (the sequence
+// number of the last exchange a peer has pushed for that parity).  Every rank writes its window into slot [parity][its rank] of
+// EVERY rank's buffer (its own included) — world concurrent writes over the direct links, 90 KB each — then raises its flag in every
+// buffer (system-scope release); the receiver waits for all flags of the parity (system-scope acquire, bounded spin) and sums the slots
+// in rank order into its window: one hop, no ring.  Two parities suffice: a rank can only be one exchange ahead of a peer (its next
+// wait needs that peer's next flag).  Buffers are uncached device memory, so a peer's writes are never shadowed by a stale L2 line.
+struct P2PPushArgs { const long long* window; unsigned long long* peer[DQL_P2P_MAX_RANKS]; int rank, world, parity; };
+DQL_DEV unsigned long long* p2p_slot(unsigned long long* buf, int world, int parity, int r) { return buf + ((size_t)parity * world + r) * DQL_ACC_LEN; }
+DQL_DEV unsigned long long* p2p_flags(unsigned long long* buf, int world, int parity) { return buf + (size_t)2 * world * DQL_ACC_LEN + (size_t)parity * DQL_P2P_MAX_RANKS; }
+__global__ void k_p2p_push(P2PPushArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= DQL_ACC_LEN) return;
+  const unsigned long long v = (unsigned long long)a.window[c];
+  for (int r = 0; r < a.world; ++r) __builtin_nontemporal_store(v, &p2p_slot(a.peer[r], a.world, a.parity, a.rank)[c]);
+}
+// after the push kernel has completed (stream order: its writes are released at the kernel boundary)
+__global__ void k_p2p_signal(P2PPushArgs a, unsigned long long seq) {
+  const int r = threadIdx.x;
+  if (r < a.world) __hip_atomic_store(&p2p_flags(a.peer[r], a.world, a.parity)[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_p2p_wait_sum(unsigned long long* mine, long long* window, int world, int parity, unsigned long long seq, int* status) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    int good = 1;
+    const unsigned long long* f = p2p_flags(mine, world, parity);
+    for (int r = 0; r < world && good; ++r) {
+      long long spins = 0;  // every wave reaches an exit: ~seconds of polling, then the exchange is reported as failed
+      while (__hip_atomic_load(&f[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        if (++spins > 40000000ll) { good = 0; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (!good) atomicExch(status, 1);
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= DQL_ACC_LEN) return;
+  unsigned long long sum = 0;
+  for (int r = 0; r < world; ++r) sum += __builtin_nontemporal_load(&p2p_slot(mine, world, parity, r)[c]);
+  window[c] = (long long)sum;
+}
+
 struct dql_ctx {
   dql_config cfg;
   int device = 0;
@@ -538,6 +583,14 @@ struct dql_ctx {
   const uint8_t* ext_actions = nullptr;  // caller-owned device actions of the next external step (dql_step_dev), else d_actions
   long long window_launches = 0; // training launches whose accumulators the window holds (windowed mode)
   struct dql_comm* comm = nullptr;  // attached RCCL communicator (not owned)
+  // one-shot peer-to-peer exchange (dql_p2p_*): this rank's exchange buffer (uncached, exported over HIP IPC), the peers' mapped
+  // buffers, and the exchange counter every rank advances in lock-step
+  int p2p_rank = -1, p2p_world = 0;
+  unsigned long long* p2p_buf = nullptr;
+  unsigned long long* p2p_peer[DQL_P2P_MAX_RANKS] = {nullptr};
+  bool p2p_opened[DQL_P2P_MAX_RANKS] = {false};
+  int* p2p_status = nullptr;  // device word: 0 = every wait so far saw its peers, 1 = a wait gave up
+  unsigned long long p2p_seq = 0;
   std::vector<hipEvent_t> sev;   // event pairs around the exchanges while the kernel timer is armed
 };
 
@@ -820,7 +873,8 @@ int dql_destroy(dql_ctx* x) {
   if (x->stream) (void)hipStreamSynchronize(x->stream);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
   for (hipEvent_t e : x->sev) (void)hipEventDestroy(e);
-  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog, x->d_mask};
+  for (int r = 0; r < DQL_P2P_MAX_RANKS; ++r) if (x->p2p_opened[r] && x->p2p_peer[r]) (void)hipIpcCloseMemHandle(x->p2p_peer[r]);
+  void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog, x->d_mask, x->p2p_buf, x->p2p_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -1608,6 +1662,78 @@ int dql_allreduce_window(dql_ctx* x) {
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, x->stream)); x->sev.push_back(e0);
   }
   NCCL_TRY(g_rccl.AllReduce(x->window, x->window, (size_t)DQL_ACC_LEN, ncclInt64, ncclSum, x->comm->nccl, x->stream));
+  return DQL_OK;
+}
+
+// ---- one-shot peer-to-peer exchange ----
+int dql_p2p_create(dql_ctx* x, int32_t rank, int32_t world, uint8_t* handle_out) {
+  CHECK_CTX(x);
+  if (!handle_out) return fail(DQL_EINVAL, "null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == DQL_P2P_HANDLE_BYTES, "DQL_P2P_HANDLE_BYTES must be the size of hipIpcMemHandle_t");
+  if (world < 1 || world > DQL_P2P_MAX_RANKS || rank < 0 || rank >= world) return fail(DQL_EINVAL, "rank must be in 0 .. world-1, world at most DQL_P2P_MAX_RANKS");
+  if (x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_create: this context already has an exchange buffer");
+  HIP_TRY(hipSetDevice(x->device));
+  const size_t words = (size_t)2 * world * DQL_ACC_LEN + (size_t)2 * DQL_P2P_MAX_RANKS;
+  if (hipExtMallocWithFlags((void**)&x->p2p_buf, words * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) { x->p2p_buf = nullptr; return fail(DQL_ENOMEM, "hipExtMallocWithFlags(exchange buffer) failed"); }
+  if (hipMalloc((void**)&x->p2p_status, sizeof(int)) != hipSuccess) { x->p2p_status = nullptr; return fail(DQL_ENOMEM, "hipMalloc failed"); }
+  HIP_TRY(hipMemsetAsync(x->p2p_buf, 0, words * sizeof(unsigned long long), x->stream));
+  HIP_TRY(hipMemsetAsync(x->p2p_status, 0, sizeof(int), x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, x->p2p_buf));
+  memcpy(handle_out, &h, sizeof(h));
+  x->p2p_rank = rank; x->p2p_world = world; x->p2p_seq = 0;
+  x->p2p_peer[rank] = x->p2p_buf;
+  return DQL_OK;
+}
+int dql_p2p_connect(dql_ctx* x, const uint8_t* all_handles) {
+  CHECK_CTX(x);
+  if (!all_handles) return fail(DQL_EINVAL, "null pointer");
+  if (!x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_connect: call dql_p2p_create first");
+  HIP_TRY(hipSetDevice(x->device));
+  for (int r = 0; r < x->p2p_world; ++r) {
+    if (r == x->p2p_rank || x->p2p_opened[r]) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, all_handles + (size_t)r * DQL_P2P_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(DQL_EHIP, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+    x->p2p_peer[r] = (unsigned long long*)ptr; x->p2p_opened[r] = true;
+  }
+  return DQL_OK;
+}
+int dql_p2p_exchange_window(dql_ctx* x) {
+  CHECK_CTX(x);
+  if (!x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_exchange_window: no exchange buffer (dql_p2p_create / dql_p2p_connect)");
+  if (!x->windowed) return fail(DQL_ESTATE, "dql_p2p_exchange_window needs windowed accumulation (dql_set_windowed)");
+  for (int r = 0; r < x->p2p_world; ++r) if (!x->p2p_peer[r]) return fail(DQL_ESTATE, "dql_p2p_exchange_window: not connected to every peer (dql_p2p_connect)");
+  HIP_TRY(hipSetDevice(x->device));
+  { int rc = flush_pending(x); if (rc) return rc; }  // the last launch's accumulators enter the window here
+  if (x->kernel_timer) {
+    if (x->sev.size() & 1) { (void)hipEventDestroy(x->sev.back()); x->sev.pop_back(); }
+    hipEvent_t e0 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, x->stream)); x->sev.push_back(e0);
+  }
+  const unsigned long long seq = ++x->p2p_seq;
+  P2PPushArgs a;
+  a.window = x->window; a.rank = x->p2p_rank; a.world = x->p2p_world; a.parity = (int)(seq & 1);
+  for (int r = 0; r < DQL_P2P_MAX_RANKS; ++r) a.peer[r] = r < x->p2p_world ? x->p2p_peer[r] : nullptr;
+  const int B = 256, G = (DQL_ACC_LEN + B - 1) / B;
+  hipLaunchKernelGGL(k_p2p_push, dim3(G), dim3(B), 0, x->stream, a);
+  hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, x->stream, a, seq);
+  hipLaunchKernelGGL(k_p2p_wait_sum, dim3(G), dim3(B), 0, x->stream, x->p2p_buf, x->window, x->p2p_world, a.parity, seq, x->p2p_status);
+  HIP_TRY(hipGetLastError());
+  return DQL_OK;
+}
+int dql_p2p_status(dql_ctx* x, int32_t* failed) {
+  CHECK_CTX(x);
+  if (!failed) return fail(DQL_EINVAL, "null pointer");
+  if (!x->p2p_status) { *failed = 0; return DQL_OK; }
+  HIP_TRY(hipSetDevice(x->device));
+  int v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, x->p2p_status, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  *failed = v;
   return DQL_OK;
 }
 

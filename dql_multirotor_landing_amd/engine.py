@@ -174,6 +174,27 @@ class Engine:
     def allreduce_window(self):
         _lib.check(self.lib.dql_allreduce_window(self._h))
 
+    # ---- one-shot peer-to-peer exchange (include/dql.h dql_p2p_*) ----
+    def p2p_create(self, rank: int, world: int) -> bytes:
+        """allocates this rank's exchange buffer; returns its 64-byte HIP IPC handle (to be gathered from all ranks)"""
+        h = (C.c_uint8 * _lib.P2P_HANDLE_BYTES)()
+        _lib.check(self.lib.dql_p2p_create(self._h, int(rank), int(world), h))
+        return bytes(h)
+
+    def p2p_connect(self, handles):
+        """handles: every rank's handle, in rank order"""
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _lib.check(self.lib.dql_p2p_connect(self._h, buf))
+
+    def p2p_exchange_window(self):
+        _lib.check(self.lib.dql_p2p_exchange_window(self._h))
+
+    def p2p_failed(self) -> bool:
+        v = C.c_int32(0)
+        _lib.check(self.lib.dql_p2p_status(self._h, C.byref(v)))
+        return bool(v.value)
+
     def sync_time_ms(self):
         ms = C.c_double(); n = C.c_int64()
         _lib.check(self.lib.dql_sync_time_ms(self._h, C.byref(ms), C.byref(n)))

@@ -243,6 +243,22 @@ int dql_comm_barrier(dql_comm* comm);
  * that follows, dql_apply_accum, is stream-ordered behind it).  Flushes first.  NULL detaches. */
 int dql_attach_comm(dql_ctx* ctx, dql_comm* comm_or_null);
 int dql_allreduce_window(dql_ctx* ctx);
+
+/* ---- one-shot peer-to-peer exchange (second step; no counterpart in the reference) ----
+ * The same sum of the window accumulators without a collective: every rank pushes its 90 KB window into a slot of EVERY rank's
+ * exchange buffer (HIP IPC mappings of uncached device memory: world concurrent one-hop writes over the direct xGMI links), raises
+ * a flag there, waits for its peers' flags and adds the slots up in rank order.  Call order on every rank:
+ *   dql_p2p_create(ctx, rank, world, handle)  -> 64-byte IPC handle of this rank's buffer; gather all ranks' handles (any way:
+ *   dql_comm_allgather_u64, files, ...), dql_p2p_connect(ctx, handles in rank order), then per exchange
+ *   dql_p2p_exchange_window(ctx) (asynchronous, on the context's stream; includes the flush) followed by dql_apply_accum(ctx) —
+ *   the drop-in for dql_allreduce_window.  A peer that never shows up makes the wait give up after a few seconds of polling instead
+ *   of hanging the GPU: dql_p2p_status reports it (failed = 1) and the window is then NOT the sum.  world <= DQL_P2P_MAX_RANKS. */
+#define DQL_P2P_HANDLE_BYTES 64
+#define DQL_P2P_MAX_RANKS 8
+int dql_p2p_create(dql_ctx* ctx, int32_t rank, int32_t world, uint8_t* handle_out);
+int dql_p2p_connect(dql_ctx* ctx, const uint8_t* all_handles);
+int dql_p2p_exchange_window(dql_ctx* ctx);
+int dql_p2p_status(dql_ctx* ctx, int32_t* failed);
 /* average device time of the exchanges (all-reduce + fold) made while the kernel timer was armed (dql_kernel_timer) */
 int dql_sync_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* syncs);
 

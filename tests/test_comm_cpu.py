@@ -67,3 +67,23 @@ def test_bench_gpus_2_without_two_gpus_fails_loudly():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "3", "--no-cpu-baseline", "--no-curriculum"], cwd=ROOT,
                        env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 2 and "launcher started 2" in r.stderr
+
+
+def test_gather_via_files_two_ranks(tmp_path, monkeypatch):
+    """comm.gather_via_files: the bootstrap all-gather of the peer-to-peer exchange's IPC handles (no collective library involved):
+    payloads come back in rank order on every rank, and the data files are gone afterwards."""
+    import threading
+    from dql_multirotor_landing_amd import comm
+    monkeypatch.setenv("DQL_COMM_ID_FILE", str(tmp_path / "boot.id"))
+    res = {}
+
+    def run(rank):
+        res[rank] = comm.gather_via_files("t0", rank, 2, bytes([rank]) * 64, timeout_s=30)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert res[0] == res[1] == [bytes([0]) * 64, bytes([1]) * 64]
+    assert not list(tmp_path.glob("*.bin"))

@@ -315,6 +315,70 @@ def test_rccl_two_ranks_equal_one_process(tmp_path):
     assert cnt.sum() > 0
 
 
+_P2P_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.dist import P2PWindowReducer, ShardedRunner, shard_range
+from dql_multirotor_landing_amd.engine import Engine
+n_total, out, dev = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+lo, hi = shard_range(n_total, rank, world)
+eng = Engine(DqlConfig(dtype=F32, t_max=5.0), hi - lo, seed=42, device=dev, env_id_offset=lo)
+eng.set_option("periods_per_launch", 2)
+run = ShardedRunner(eng, P2PWindowReducer(eng, rank, world), sync_period=2)
+run.train_steps(40, 1.0); run.train_steps(41, 0.2); run.sync()
+assert not eng.p2p_failed(), "a peer never showed up"
+qa, qb, cnt = eng.get_tables()
+reals, ints = eng.get_fields()
+np.savez(f"{out}/rank{rank}.npz", qa=qa, qb=qb, count=cnt, reals=reals, ints=ints, decisions=eng.stats()["decisions"])
+assert "torch" not in sys.modules
+print("RANK_OK")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_exchange_ranks_sharing_one_gpu_equal_one_process(tmp_path, world):
+    """The one-shot peer-to-peer exchange (dql_p2p_*: HIP IPC mappings of uncached exchange buffers, flags with system-scope
+    release / acquire, slots summed in rank order) with `world` rank PROCESSES — all on GPU 0, which is what a 1-GPU box can host; on a
+    node they would sit on different GPUs — against one process with all the envs on the same schedule: tables, visit counts and
+    every env's state bit for bit.  Also the first test in which several HIP-engine ranks really run side by side."""
+    import subprocess
+    import sys
+    from dql_multirotor_landing_amd.dist import LocalWindowReducer, ShardedRunner
+    from dql_multirotor_landing_amd.engine import Engine
+    root = Path(__file__).resolve().parent.parent
+    n_total = 3000
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), DQL_COMM_ID_FILE=str(tmp_path / "boot.id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _P2P_RANK_SCRIPT, str(n_total), str(tmp_path), "0"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=300))
+    finally:
+        for pr in procs:  # exactly the processes started here
+            if pr.poll() is None:
+                pr.kill()
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0 and "RANK_OK" in so, so[-1000:] + se[-3000:]
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    single = Engine(DqlConfig(dtype=F32, t_max=5.0), n_total, seed=42)
+    single.set_option("periods_per_launch", 2)
+    run = ShardedRunner(single, LocalWindowReducer(single), sync_period=2)
+    run.train_steps(40, 1.0); run.train_steps(41, 0.2); run.sync()
+    qa, qb, cnt = single.get_tables()
+    for r in ranks:
+        assert np.array_equal(r["qa"], qa) and np.array_equal(r["qb"], qb) and np.array_equal(r["count"], cnt)
+    assert sum(int(r["decisions"]) for r in ranks) == single.stats()["decisions"]
+    reals, ints = single.get_fields()
+    assert np.array_equal(np.concatenate([r["ints"] for r in ranks], axis=1), ints)
+    assert np.array_equal(np.concatenate([r["reals"] for r in ranks], axis=1), reals)
+    assert cnt.sum() > 0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` starts N ranks itself; on a box with fewer GPUs it must fail loudly, never print n_gpus: 1."""
     import subprocess
