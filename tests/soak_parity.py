@@ -4,7 +4,7 @@ set, axes, trajectory, per-env platform, observation noise, fold semantics, wind
 launch), every field and
 table compared bit for bit after every chunk.  The regular suite pins chosen points; this sweeps the space once.
 
-    python tools/soak_parity.py [N_CONFIGS=24] [SEED=0]
+    python tests/soak_parity.py [N_CONFIGS=24] [SEED=0]
 """
 import json, sys
 from pathlib import Path
