@@ -611,9 +611,10 @@ template <typename T> DQL_DEV T place_axis(int init_mode, T x0, T mp, T p_max) {
 // functions above (quat_to_R, yaw_cs, pid_output x 2, attitude, plant_step, rotor_filter, platform_contact) — so the CPU oracle
 // needs no change and parity stays bit-exact — but issued two at a time as v_pk_mul / v_pk_add / v_pk_fma_f32 on register PAIRS
 // that are laid out for it once per agent period: quaternion (w,x) (y,z); body rates, velocity, position (0,1) + the third
-// component; rotors by arm (0,2) (1,3); the two PIDs as one pair of controllers (v_z, yaw); platform (x,y) (u,v).  gfx950 issues a
-// wave64 f32 VALU instruction in ~4 cycles whether it does one operation per lane or two (profiles/r2_valu_rate.jsonl), so
-// every pair halves its share of the step.  Swizzles (swap, broadcast) fold into op_sel, sign flips into neg modifiers.
+// component; rotors by arm (0,2) (1,3); the two PIDs as one pair of controllers (v_z, yaw); platform (x,y) (u,v).  For a wave that is
+// ALONE on its SIMD a packed instruction costs about what a scalar one does (2.4-2.6 ns against 2.2-2.45, profiles/r2_pk_variants.jsonl),
+// so every pair halves its share of the step; beside a second wave it costs two issue slots and the layout loses — the host picks it
+// for batches of at most one env wave per SIMD only.  Swizzles (swap, broadcast) fold into op_sel, sign flips into neg modifiers.
 // ---------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 DQL_DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
