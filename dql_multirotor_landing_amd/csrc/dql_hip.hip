@@ -523,9 +523,9 @@ __global__ void k_p2p_wait_sum(unsigned long long* mine, long long* window, int 
     int good = 1;
     const unsigned long long* f = p2p_flags(mine, world, parity);
     for (int r = 0; r < world && good; ++r) {
-      long long spins = 0;  // every wave reaches an exit: ~seconds of polling, then the exchange is reported as failed
+      long long spins = 0;  // every wave reaches an exit: ~10 s of polling, then the exchange is reported as failed
       while (__hip_atomic_load(&f[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        if (++spins > 40000000ll) { good = 0; break; }
+        if (++spins > 10000000ll) { good = 0; break; }
         __builtin_amdgcn_s_sleep(8);
       }
     }
