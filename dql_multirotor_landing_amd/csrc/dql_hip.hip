@@ -517,15 +517,15 @@ __global__ void k_p2p_signal(P2PPushArgs a, unsigned long long seq) {
   const int r = threadIdx.x;
   if (r < a.world) __hip_atomic_store(&p2p_flags(a.peer[r], a.world, a.parity)[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_p2p_wait_sum(unsigned long long* mine, long long* window, int world, int parity, unsigned long long seq, int* status) {
+__global__ void k_p2p_wait_sum(unsigned long long* mine, long long* window, int world, int parity, unsigned long long seq, int* status, long long spin_limit) {
   __shared__ int ok;
   if (threadIdx.x == 0) {
     int good = 1;
     const unsigned long long* f = p2p_flags(mine, world, parity);
     for (int r = 0; r < world && good; ++r) {
-      long long spins = 0;  // every wave reaches an exit: ~10 s of polling, then the exchange is reported as failed
+      long long spins = 0;  // every wave reaches an exit: spin_limit polls (default 10 M, ~10 s), then the exchange is reported as failed
       while (__hip_atomic_load(&f[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        if (++spins > 10000000ll) { good = 0; break; }
+        if (++spins > spin_limit) { good = 0; break; }
         __builtin_amdgcn_s_sleep(8);
       }
     }
@@ -591,6 +591,7 @@ struct dql_ctx {
   bool p2p_opened[DQL_P2P_MAX_RANKS] = {false};
   int* p2p_status = nullptr;  // device word: 0 = every wait so far saw its peers, 1 = a wait gave up
   unsigned long long p2p_seq = 0;
+  long long p2p_spin_limit = 10000000ll;  // option "p2p_spin_limit"
   std::vector<hipEvent_t> sev;   // event pairs around the exchanges while the kernel timer is armed
 };
 
@@ -1307,6 +1308,11 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
     x->tick = value;
     return DQL_OK;
   }
+  if (!strcmp(name, "p2p_spin_limit")) {
+    if (value < 1000) return fail(DQL_EINVAL, "p2p_spin_limit must be at least 1000 polls");
+    x->p2p_spin_limit = value;
+    return DQL_OK;
+  }
   if (!strcmp(name, "block")) {
     if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512) return fail(DQL_EINVAL, "block must be 0, 64, 128, 256 or 512");
     if (value == 512 && x->dtype != DQL_F32) return fail(DQL_EINVAL, "block 512 serves float32 contexts");
@@ -1721,7 +1727,7 @@ int dql_p2p_exchange_window(dql_ctx* x) {
   const int B = 256, G = (DQL_ACC_LEN + B - 1) / B;
   hipLaunchKernelGGL(k_p2p_push, dim3(G), dim3(B), 0, x->stream, a);
   hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, x->stream, a, seq);
-  hipLaunchKernelGGL(k_p2p_wait_sum, dim3(G), dim3(B), 0, x->stream, x->p2p_buf, x->window, x->p2p_world, a.parity, seq, x->p2p_status);
+  hipLaunchKernelGGL(k_p2p_wait_sum, dim3(G), dim3(B), 0, x->stream, x->p2p_buf, x->window, x->p2p_world, a.parity, seq, x->p2p_status, x->p2p_spin_limit);
   HIP_TRY(hipGetLastError());
   return DQL_OK;
 }

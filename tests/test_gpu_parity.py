@@ -379,6 +379,51 @@ def test_p2p_exchange_ranks_sharing_one_gpu_equal_one_process(tmp_path, world):
     assert cnt.sum() > 0
 
 
+_P2P_LONELY_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.dist import P2PWindowReducer
+from dql_multirotor_landing_amd.engine import Engine
+rank = int(os.environ["RANK"])
+eng = Engine(DqlConfig(dtype=F32), 256, seed=1, env_id_offset=256 * rank)
+red = P2PWindowReducer(eng, rank, 2)
+eng.set_windowed(True)
+if rank == 0:
+    eng.set_option("p2p_spin_limit", 200000)
+    eng.train_steps(4, 1.0)
+    t0 = time.time(); red.all_reduce(); eng.sync(); dt = time.time() - t0
+    assert eng.p2p_failed(), "the wait must give up when the peer never pushes"
+    print("GAVE_UP %.2f" % dt)
+else:
+    time.sleep(6)   # connected, but never takes part in the exchange
+    print("IDLE_OK")
+"""
+
+
+def test_p2p_exchange_gives_up_on_a_missing_peer(tmp_path):
+    """A rank whose peer never pushes: the wait kernel's poll loop is bounded (option "p2p_spin_limit"), every wave exits, the failure is
+    reported by dql_p2p_status — no hang, no GPU reset."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", DQL_COMM_ID_FILE=str(tmp_path / "boot.id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _P2P_LONELY_SCRIPT], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=120))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert procs[0].returncode == 0 and "GAVE_UP" in outs[0][0], outs[0][0][-500:] + outs[0][1][-2000:]
+    assert procs[1].returncode == 0 and "IDLE_OK" in outs[1][0], outs[1][1][-2000:]
+    assert float(outs[0][0].split("GAVE_UP")[1].split()[0]) < 5.0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` starts N ranks itself; on a box with fewer GPUs it must fail loudly, never print n_gpus: 1."""
     import subprocess
