@@ -12,7 +12,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
 OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 P2P_MAX_RANKS = 8
@@ -98,6 +98,7 @@ SYMBOLS = {
     "dql_discretise": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dql_manager_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _u64, _vp]),
+    "dql_plant_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "dql_place": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),

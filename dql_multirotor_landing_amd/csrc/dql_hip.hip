@@ -466,6 +466,31 @@ __global__ void k_manager_run(SimK<T> c, long long n_series, long long n_ticks, 
     o[6] = e.vz_state; o[7] = e.yw_state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;
   }
 }
+// the plant of the fused kernel (plant_step + rotor_filter + platform_contact) replayed open loop, one lane per series (dql_plant_run)
+template <typename T>
+__global__ void k_plant_run(SimK<T> c, long long n_series, long long n_ticks, const double* init, const double* rotor_cmd, double* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_series) return;
+  Env<T> e;
+  memset(&e, 0, sizeof(e));
+  const double* s0 = init + i * 21;
+  for (int k = 0; k < 3; ++k) { e.p[k] = (T)s0[k]; e.v[k] = (T)s0[3 + k]; e.w[k] = (T)s0[10 + k]; }
+  for (int k = 0; k < 4; ++k) { e.q[k] = (T)s0[6 + k]; e.om[k] = (T)s0[13 + k]; }
+  e.mp_x = (T)s0[17]; e.mp_y = (T)s0[18]; e.mp_u = (T)s0[19]; e.mp_v = (T)s0[20];
+  for (long long t = 0; t < n_ticks; ++t) {
+    const double* r = rotor_cmd + (i * n_ticks + t) * 4;
+    const T cmd[4] = {(T)r[0], (T)r[1], (T)r[2], (T)r[3]};
+    T R[9];
+    quat_to_R(e.q, R);
+    plant_step(c, e, R);
+    rotor_filter(c, e, cmd);
+    platform_contact(c, e);
+    double* o = out + (i * n_ticks + t) * 20;
+    for (int k = 0; k < 3; ++k) { o[k] = e.p[k]; o[3 + k] = e.v[k]; o[10 + k] = e.w[k]; }
+    for (int k = 0; k < 4; ++k) { o[6 + k] = e.q[k]; o[13 + k] = e.om[k]; }
+    o[17] = e.mp_x; o[18] = e.mp_y; o[19] = (e.flags & FL_CONTACT) ? 1.0 : 0.0;
+  }
+}
 template <typename T> __global__ void k_place(int init_mode, T p_max, const double* x0, const double* mp, long long n, double* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (double)place_axis(init_mode, (T)x0[i], (T)mp[i], p_max);
@@ -1428,6 +1453,24 @@ int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t
   else hipLaunchKernelGGL(k_manager_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(c2), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const uint8_t*)b.p, (unsigned long long)seed, (double*)o.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, o.p, cells * 12 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* init, const double* rotor_cmd, double* out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n_series < 0 || n_ticks < 0 || ((n_series > 0 && n_ticks > 0) && (!init || !rotor_cmd || !out))) return fail(DQL_EINVAL, "null array");
+  if (n_series == 0 || n_ticks == 0) return DQL_OK;
+  const size_t cells = (size_t)n_series * (size_t)n_ticks;
+  for (size_t k = 0; k < cells * 4; ++k) if (!(rotor_cmd[k] >= 0.0)) return fail(DQL_EINVAL, "rotor commands must be >= 0 (the attitude law commands sqrt(max(w^2, 0)))");
+  OP_PROLOGUE(device)
+  DevBuf a, b, o;
+  UP(a, init, (size_t)n_series * 21 * sizeof(double)); UP(b, rotor_cmd, cells * 4 * sizeof(double));
+  if (o.alloc(cells * 20 * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const unsigned grid = (unsigned)((n_series + 63) / 64);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_plant_run<float>, dim3(grid), dim3(64), 0, 0, make_simk<float>(*cfg), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const double*)b.p, (double*)o.p);
+  else hipLaunchKernelGGL(k_plant_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(*cfg), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const double*)b.p, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, o.p, cells * 20 * sizeof(double), hipMemcpyDeviceToHost));
   return DQL_OK;
 }
 

@@ -59,6 +59,19 @@ def manager_run(cfg: DqlConfig, series, contact, seed: int = 0, device: int = 0)
     return out
 
 
+def plant_run(cfg: DqlConfig, init, rotor_cmd, device: int = 0) -> np.ndarray:
+    """The plant of the fused step (rotor forces + rigid body + rotor filter + platform extrapolation / contact latch: what stands in
+    for gazebo_motor_model.cpp + ODE) open loop: `init` [n_series][21] (p, v, quaternion wxyz, body rates, rotor speeds, platform
+    x y u v), `rotor_cmd` [n_series][n_ticks][4] -> [n_series][n_ticks][20] state after every 500 Hz tick (include/dql.h)."""
+    a = _f64(init); b = _f64(rotor_cmd)
+    if a.ndim != 2 or a.shape[1] != 21 or b.ndim != 3 or b.shape[2] != 4 or b.shape[0] != a.shape[0]:
+        raise ValueError("init must be [n_series][21], rotor_cmd [n_series][n_ticks][4]")
+    out = np.zeros(b.shape[:2] + (20,))
+    cc = cfg.to_c()
+    _lib.check(_lib.load().dql_plant_run(C.byref(cc), device, b.shape[0], b.shape[1], _p(a), _p(b), _p(out)))
+    return out
+
+
 def place(cfg: DqlConfig, x0, mp, device: int = 0) -> np.ndarray:
     """Drone start coordinate for (random offset, platform coordinate) pairs: the reset placement selected by cfg.init_uniform."""
     x0, mp = _f64(x0), _f64(mp)

@@ -30,7 +30,12 @@ Build-specific keywords (not in the reference): n_envs, device, dtype, mode, chu
 promotion_rule, judge_envs, sync_period, max_steps_per_level, eps_floor, quirks (override of the mode's quirk set, include/dql.h DQL_Q_*), eps_episode_scale (the reference's
 exploration schedule counts episodes of ONE env: 800 random episodes, 1 200 decaying; N envs finish that many in their first
 generation, so `eps_episode_scale = s` reads the schedule at episodes / s), checkpoint_env_state, periods_per_launch (agent periods
-per kernel launch, engine option of the same name: the tables the envs act on are refreshed once per launch; 1 = every period).
+per kernel launch, engine option of the same name: the tables the envs act on are refreshed once per launch; 1 = every period),
+eps_tail (None = the reference: level 0 keeps exploring at 0.01 once the schedule's decay has ended, pkg/trainer.py:121-131; a number
+replaces that tail.  Measured on 32 768 envs, tools/exp_level0.py -> profiles/r3_level0_eps_tail.jsonl: tables LEARNT from the 1 % of
+exploratory transitions fly 58 % of level 0's episodes into the goal state and 41 % out of the fly zone, whether they then ACT with
+eps 0.01 or 0; the same tables learning on with eps 0 reach 99.4 % within 250 agent periods.  The paper's text ends the schedule at
+episode 2000; the later levels run at eps 0 in both).
 `max_num_episodes=None` (default) is the reference's 50 000 per level, but at least 384 per env: the reference's figure is
 sized for one env, and a level has to last until the judged envs have flown a few hundred episodes each.
 `judge_envs` (default 1): whose episodes feed the promotion deque.  1 is the reference's own situation — ONE env's episodes in the
@@ -79,7 +84,7 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
-               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch")
+               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after")
 
 
 class Trainer:
@@ -92,7 +97,7 @@ class Trainer:
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
-                 periods_per_launch: int = 1, comm=None, reducer_factory=None) -> None:
+                 periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -131,6 +136,8 @@ class Trainer:
         self._judge_envs = self._n_envs if judge_envs is None else max(1, min(int(judge_envs), self._n_envs))
         self._checkpoint_env_state = bool(checkpoint_env_state)
         self._periods_per_launch = int(periods_per_launch)
+        self._eps_tail = None if eps_tail is None else float(eps_tail)
+        self._eps_tail_after = float(eps_tail_after)
         if not 1 <= self._periods_per_launch <= 8 or self._chunk_steps % self._periods_per_launch:
             raise ValueError("periods_per_launch must be in 1..8 and divide chunk_steps")
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
@@ -370,7 +377,10 @@ class Trainer:
             promoted_at = None
             info: Dict[str, Any] = {}
             while episodes < self._max_num_episodes:
-                eps = max(self.exploration_rate(int(episodes / self._eps_episode_scale), k), self._eps_floor)  # scale 1, floor 0: the reference schedule
+                sched_episode = int(episodes / self._eps_episode_scale)
+                eps = max(self.exploration_rate(sched_episode, k), self._eps_floor)  # scale 1, floor 0: the reference schedule
+                if self._eps_tail is not None and k == 0 and sched_episode >= 2000 and episodes >= self._eps_tail_after * self._n_envs:
+                    eps = self._eps_tail  # what follows the schedule's decay (the reference stays at 0.01 for the rest of level 0)
                 runner.train_steps(self._chunk_steps, eps)
                 steps += self._chunk_steps
                 s = eng.stats()

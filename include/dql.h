@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DQL_ABI_VERSION 2
+#define DQL_ABI_VERSION 3
 
 typedef enum dql_status {
   DQL_OK = 0,
@@ -316,6 +316,17 @@ int dql_mdp_transition(const dql_config* cfg, int device, int64_t n, uint32_t st
  * Noise (cfg noise_*_sd > 0) comes from the Philox stream of (seed, series). */
 int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* in, const uint8_t* contact,
                     uint64_t seed, double* out);
+/* The plant of the fused step — what replaces Gazebo's motor-model plugin + ODE — replayed OPEN LOOP for n_series independent
+ * series of n_ticks 500 Hz physics ticks, with the device functions the step kernel runs, in the kernel's order: rotation matrix of
+ * the attitude quaternion; forces and moments of the CURRENT rotor speeds (thrust, rotor drag, rolling moment, drag torque:
+ * rotors_gazebo_plugins/src/gazebo_motor_model.cpp:434-482) and one semi-implicit Euler step of the rigid body (dt, g:
+ * worlds/basic.world:36-73); first-order rotor filter towards min(command, max_rot_velocity) (common.h:147-183,
+ * gazebo_motor_model.cpp:358-364); platform extrapolation and the bumper-contact latch.  No controller, no MDP.
+ * init double[n_series][21] = drone p(3), v(3), quaternion w x y z, body rates(3), rotor speeds(4), platform x y u v;
+ * rotor_cmd double[n_series][n_ticks][4] commanded rotor speeds (rad/s, >= 0); out double[n_series][n_ticks][20] = p(3), v(3),
+ * quaternion(4), body rates(3), rotor speeds(4), platform x y, contact latch (0 / 1) AFTER each tick.  Exists so that tests can hold
+ * the plant against closed forms (tests/test_plant_closed_forms.py); Gazebo itself cannot run here (parity vs Gazebo: unpinned). */
+int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* init, const double* rotor_cmd, double* out);
 /* start coordinate of the drone along one axis for n (random offset x0, platform coordinate) pairs: the placement arithmetic of
  * TrainingLandingEnv.reset / SimulationLandingEnv.reset selected by cfg->init_uniform (see dql_config) */
 int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out);

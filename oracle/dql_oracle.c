@@ -968,6 +968,28 @@ EXPORT void ORC(manager_run)(const dql_config* c, int64_t n_ticks, const double*
     o[6] = e.vz.state; o[7] = e.yaw.state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;
   }
 }
+/* the plant alone, open loop (include/dql.h dql_plant_run): per 500 Hz tick the rotor forces of the current rotor speeds + one
+ * semi-implicit Euler step + rotor filter (motor_and_body), then platform extrapolation + contact latch.  init[21] = p v q(wxyz) w
+ * om platform x y u v; cmd[n_ticks][4]; out[n_ticks][20] = p v q w om platform x y contact */
+EXPORT void ORC(plant_run)(const dql_config* c, int64_t n_ticks, const double* init, const double* cmd_in, double* out) {
+  simc_t s; simc_init(&s, c);
+  env_t e; memset(&e, 0, sizeof(e));
+  for (int k = 0; k < 3; ++k) { e.p[k] = (REAL)init[k]; e.v[k] = (REAL)init[3 + k]; e.w[k] = (REAL)init[10 + k]; }
+  for (int k = 0; k < 4; ++k) { e.q[k] = (REAL)init[6 + k]; e.om[k] = (REAL)init[13 + k]; }
+  e.mp_x = (REAL)init[17]; e.mp_y = (REAL)init[18]; e.mp_u = (REAL)init[19]; e.mp_v = (REAL)init[20];
+  for (int64_t t = 0; t < n_ticks; ++t) {
+    const REAL cmd[4] = {(REAL)cmd_in[t * 4], (REAL)cmd_in[t * 4 + 1], (REAL)cmd_in[t * 4 + 2], (REAL)cmd_in[t * 4 + 3]};
+    REAL R[9];
+    quat_to_R(e.q, R);
+    motor_and_body(&s, &e, R, cmd);
+    e.mp_x = FMA(e.mp_u, s.dt, e.mp_x); e.mp_y = FMA(e.mp_v, s.dt, e.mp_y);
+    if (e.p[2] - s.bottom <= s.mp_top && FABS(e.p[0] - e.mp_x) <= s.mp_hx && FABS(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+    double* o = out + t * 20;
+    for (int k = 0; k < 3; ++k) { o[k] = e.p[k]; o[3 + k] = e.v[k]; o[10 + k] = e.w[k]; }
+    for (int k = 0; k < 4; ++k) { o[6 + k] = e.q[k]; o[13 + k] = e.om[k]; }
+    o[17] = e.mp_x; o[18] = e.mp_y; o[19] = (e.flags & FL_CONTACT) ? 1.0 : 0.0;
+  }
+}
 EXPORT void ORC(place)(const dql_config* c, const double* x0, const double* mp, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = (double)place_axis(c->init_uniform, (REAL)x0[i], (REAL)mp[i], (REAL)c->p_max);
 }

@@ -380,3 +380,13 @@ def place(cfg: DqlConfig, x0, mp, dtype=None):
     cc = cfg.to_c()
     _run("place", cfg.dtype if dtype is None else dtype, C.byref(cc), _p(x0), _p(mp), C.c_int64(len(x0)), _p(out))
     return out
+
+
+def plant_run(cfg: DqlConfig, init, rotor_cmd, dtype=None):
+    """open-loop plant: init [n_series][21], rotor_cmd [n_series][n_ticks][4] -> [n_series][n_ticks][20] (dql_oracle.c plant_run)"""
+    a = _f64(init); b = _f64(rotor_cmd)
+    out = np.zeros(b.shape[:2] + (20,))
+    cc = cfg.to_c()
+    for i in range(a.shape[0]):
+        _run("plant_run", cfg.dtype if dtype is None else dtype, C.byref(cc), C.c_int64(b.shape[1]), _p(a[i]), _p(b[i]), _p(out[i]))
+    return out
