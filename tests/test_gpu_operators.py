@@ -99,6 +99,29 @@ def test_manager_run_golden_and_oracle(ops, golden_dir):
     assert many.shape == (70, 300, 12) and np.array_equal(many[:, :, 4:6], np.repeat(many[:1, :, 4:6], 70, axis=0)) and not np.array_equal(many[0, :, 0], many[1, :, 0])
 
 
+def test_plant_run_equals_oracle(ops):
+    """a26 / a27: the open-loop plant operator == its oracle twin bit for bit on random series (float64 and float32): tumbling attitudes,
+    rotor commands above the speed limit, platforms under the vehicle.  (What pins BOTH against the reference's formulas:
+    tests/test_plant_closed_forms.py.)"""
+    from dql_multirotor_landing_amd.config import F32
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    ns, nt = 130, 120
+    q = rng.normal(size=(ns, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    init = np.c_[rng.uniform(-3, 3, (ns, 2)), rng.uniform(0.4, 4, (ns, 1)), rng.uniform(-2, 2, (ns, 3)), q, rng.uniform(-3, 3, (ns, 3)),
+                 rng.uniform(0, 838, (ns, 4)), rng.uniform(-3, 3, (ns, 2)), rng.uniform(-1.6, 1.6, (ns, 2))]
+    cmd = rng.uniform(0, 1000, (ns, nt, 4))
+    for dtype in (F64, F32):
+        cfg = DqlConfig(dtype=dtype)
+        got = ops.plant_run(cfg, init, cmd)
+        want = orc.plant_run(cfg, init, cmd)
+        np.testing.assert_array_equal(got, want, err_msg=f"dtype {dtype}: HIP != oracle")
+        assert got[:, :, 19].max() == 1.0 and got[:, :, 19].min() == 0.0  # some series touch the platform, some never do
+    with pytest.raises(ValueError):
+        ops.plant_run(DqlConfig(), init, -cmd)
+    assert ops.plant_run(DqlConfig(), init[:0], cmd[:0]).shape == (0, nt, 20)
+
+
 def test_place_golden(ops, golden_dir):
     """a17 / a19 placement arithmetic of reset() on the GPU == what the reference's reset() handed to /gazebo/set_model_state."""
     z = np.load(golden_dir / "g13_env.npz")
