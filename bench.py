@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/sec of the fused UAV-landing + tabular Double-Q training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--envs E] [--dtype f32|f64] [--sync-period S]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4] [--envs E] [--dtype f32|f64] [--sync-period S]
 
-One "step" = one agent period (1/22.92 s of simulated time: 21-22 physics ticks + MDP + TD update) for every env of
-every rank.  Workload at N=1: BASELINE.json configs[1] — 4096 vectorised envs, x-axis MDP, curriculum step 0, eps 1.0,
-state resident in HBM before the timed region.  N>1: one process per GPU — started by torch.distributed.run (RANK /
-WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment) or, without a launcher, by this script itself (`--gpus N` spawns N
-child ranks before anything touches a GPU and fails if they cannot each have one); weak scaling, E envs per GPU, env
-shards with global env ids, int64 accumulator all-reduce every --sync-period steps by RCCL inside libdql_hip.so.  No
-PyTorch anywhere in this file.
+One "step" = one agent period (1/22.92 s of simulated time: 21-22 physics ticks + MDP + TD update) for every env of every rank.
+
+Workload (`--config`, default 4 at EVERY N — BASELINE.json quotes its whole-node metric on configs[4]; its per-GPU share fits one GPU):
+  4  configs[4] share: 1 048 576 envs / 8 GPUs = 131 072 envs per GPU, per-env randomised sinusoidal platforms (r_x ~ U(1,3) m,
+     t_x ~ U(0.8,1.6) m/s) + observation noise (0.25 m, 0.1 m/s, Kalman R = 0.1^2), x-axis MDP, curriculum step 0, float32 dynamics,
+     int32 packed table index; algorithmic 328 B per env-step.  `--gpus 8` = 1 048 576 global envs.
+  3  configs[3] share: 262 144 / 8 = 32 768 envs per GPU, x-axis, shared platform (320 B); its full 0 -> 4 curriculum is the
+     curriculum leg of EVERY run (`--curriculum-envs`, default 32 768 per GPU), whatever the throughput config.
+  2  configs[2]: 65 536 envs, joint x + y MDP (400 B), one GPU.
+  1  configs[1]: 4 096 envs, x-axis (320 B), one GPU — 64 waves on a 1 024-SIMD chip: reported in every single-GPU run as the
+     secondary `small_batch` block with its own roofline.
+State is resident in HBM before the timed region.  N > 1: one process per GPU — started by torch.distributed.run (RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_* in the environment) or, without a launcher, by this script itself (`--gpus N` spawns N child ranks before
+anything touches a GPU and fails if they cannot each have one); weak scaling, E envs per GPU, env shards with global env ids, int64
+accumulator all-reduce every --sync-period steps by RCCL inside libdql_hip.so.  No PyTorch anywhere in this file.
 `value` counts env-steps = (env, period) pairs in which an action was taken (reset periods are not counted).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,20 +34,60 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-ALGO_BYTES_PER_ENV_STEP = 320  # 40 four-byte words of persistent per-env state, read once + written once
-ALGO_BYTES_PER_ENV_STEP_2AXIS = 400  # 50 words in the 2-axis config
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_VALU_PEAK_TFLOPS = 157.3
 
+# algorithmic bytes per env-step = persistent per-env state words x 4 B, read once + written once per agent step
+ALGO_BYTES = {"x": 320, "x_per_env_platform": 328, "two_axis": 400}
+PRESETS = {
+    1: dict(envs=4096, two_axis=0, randomize_platform=0, noise=0, tag="configs[1]", what="4 096 vectorised envs, x-axis MDP, curriculum step 0, shared rpm platform r = 2 m, omega = 0.8 rad/s"),
+    2: dict(envs=65536, two_axis=1, randomize_platform=0, noise=0, tag="configs[2]", what="65 536 envs, joint x + y 2-axis MDP, curriculum step 0"),
+    3: dict(envs=32768, two_axis=0, randomize_platform=0, noise=0, tag="configs[3] share", what="262 144 envs / 8 GPUs = 32 768 envs per GPU, x-axis MDP, shared rpm platform (the curriculum leg runs its full 0 -> 4 schedule)"),
+    4: dict(envs=131072, two_axis=0, randomize_platform=1, noise=1, tag="configs[4] share",
+            what="1 048 576 envs / 8 GPUs = 131 072 envs per GPU, per-env randomised sinusoidal platforms (r_x ~ U(1,3) m, t_x ~ U(0.8,1.6) m/s) + observation noise "
+                 "0.25 m / 0.1 m/s with Kalman R = 0.1^2, x-axis MDP, curriculum step 0, fp32 dynamics / int32 packed table index"),
+}
 
-def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
-    """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on the host cores, bounded sample:
-    all cores (OpenMP over envs) as the headline value, one thread next to it."""
+
+def algo_bytes(two_axis: int, randomize_platform: int) -> int:
+    return ALGO_BYTES["two_axis"] if two_axis else (ALGO_BYTES["x_per_env_platform"] if randomize_platform else ALGO_BYTES["x"])
+
+
+def lib_source_sha16() -> str:
+    """Hash of the sources libdql_hip.so is built from: committed PMC figures (profiles/*_traffic.json, *_pmc_sq_summary.json) carry
+    the hash of the kernel they measured, and a figure is only quoted for the library that produced it."""
+    h = hashlib.sha256()
+    for f in ("dql_multirotor_landing_amd/csrc/dql_hip.hip", "dql_multirotor_landing_amd/csrc/dql_device.hpp", "dql_multirotor_landing_amd/csrc/dql_refk.inc", "include/dql.h"):
+        h.update((ROOT / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def flavour_key(envs: int, P: int, two_axis: int, randomize_platform: int, noise: int) -> str:
+    return f"{envs}_p{P}" + ("_2axis" if two_axis else ("_cfg4" if (randomize_platform and noise) else ""))
+
+
+def committed_profile(kind: str):
+    """the newest committed PMC summary of `kind` ("traffic" | "pmc_sq_summary") whose source stamp is this library's, else (None, why)"""
+    sha = lib_source_sha16()
+    for f in sorted((ROOT / "profiles").glob(f"r*_{kind}.json"), reverse=True):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        stamp = t.get("source_sha16")
+        if stamp == sha:
+            return t, f.name
+    return None, f"no committed profiles/r*_{kind}.json carries this library's source hash {sha} (PMC passes not re-run since the kernel changed)"
+
+
+def cpu_baseline(envs: int, steps: int, dtype: int, cfg_kw: dict):
+    """The CPU oracle (a port of the same fused step: oracle/dql_oracle.c) on the host cores, bounded sample of the SAME workload
+    flavour: all cores (OpenMP over envs) as the headline value, one thread next to it."""
     from dql_multirotor_landing_amd.config import DqlConfig
     from oracle.oracle import Oracle
 
     def run(threads, n_steps):
-        o = Oracle(DqlConfig(dtype=dtype, two_axis=two_axis), envs, seed=42, n_threads=threads)
+        o = Oracle(DqlConfig(dtype=dtype, **cfg_kw), envs, seed=42, n_threads=threads)
         o.train_steps(3, 1.0)
         d0 = o.stats_dict()["decisions"]
         t0 = time.perf_counter()
@@ -58,17 +107,29 @@ def cpu_baseline(envs: int, steps: int, dtype: int, two_axis: int = 0):
     d1, t1 = run(1, steps)
     dn, tn = run(cores, steps * min(cores, 16))
     return {"value": dn / tn, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{envs} envs x {steps * min(cores, 16)} agent periods ({dn} env-steps, {tn:.1f} s), OpenMP over envs on {cores} threads, same dtype, gcc -O2 -fopenmp",
+            "sample": f"{envs} envs of the headline workload flavour x {steps * min(cores, 16)} agent periods ({dn} env-steps, {tn:.1f} s), OpenMP over envs on {cores} threads, same dtype, gcc -O2 -fopenmp",
             "single_thread_value": d1 / t1, "single_thread_sample": f"{envs} envs x {steps} agent periods ({d1} env-steps, {t1:.1f} s)"}
 
 
+# Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
+# (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
+# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl,
+# r3_curriculum_32768_sweep1_variants.jsonl); 4 judged envs: the deque sees the episodes of 4 envs; 8 agent periods per launch and table
+# exchange every 8; eps_tail: level 0 follows the reference's exploration schedule, keeps its 0.01 floor for the first 192 episodes per
+# env and then stops exploring — tables that LEARN from the floor's exploratory transitions fly 41 % of level 0's episodes out of the fly
+# zone, the same tables learning on without them 0.6 % (profiles/r3_level0_eps_tail.jsonl); stopping right away starves the later
+# levels of visited states (profiles/r3_curriculum_sweep2_eps_tail_immediate.jsonl)
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 8, "eps_tail": 0.0, "eps_tail_after": 192}
+CURRICULUM_SYNC = 8
+CURRICULUM_SEEDS = (42, 1, 2, 3, 4, 5)  # tabular RL is seed-noisy (touchdown 85-95 % between seeds): six full curricula, each reported
+
+
 def curriculum_leg(args, comm, world, rank, dev_index, dtype):
-    """Second half of BASELINE.json's metric: wall-clock to curriculum stage 4.  The Trainer's loop (reference promotion rule:
-    100-episode deque > 0.96 or the level's episode budget runs out) on the same envs-per-GPU, sharded over the ranks of this
-    job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).  Same table schedule
-    (same sync period and periods per launch) at any N, one GPU included, so the
-    figures of a scaling sweep are the same run on more hardware.  Never fails the bench."""
-    # (sync_period CURRICULUM_SYNC: the windowed schedule also on one GPU, so that N = 1 and N = 8 run the same algorithm)
+    """Second half of BASELINE.json's metric: wall-clock to curriculum stage 4, on BASELINE configs[3]'s size (32 768 envs per GPU by
+    default, `--curriculum-envs`).  The Trainer's loop (reference promotion rule: 100-episode deque > 0.96, or the level's episode budget
+    runs out) sharded over the ranks of this job, then greedy roll-outs of the resulting stage-4 tables next to the reference's own (rank 0).
+    Same table schedule (sync period and periods per launch) at any N, one GPU included, so the figures of a scaling sweep are the
+    same run on more hardware.  Never fails the bench."""
     import tempfile
     try:
         from dql_multirotor_landing_amd.config import Q_PAPER
@@ -81,13 +142,14 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
             g_ = simulation.evaluate(tables, 4096, 4, flavour="training", quirks=Q_PAPER, device=dev_index)
             return {"touchdown_rate": h["TERMINAL_CONTACT"] / 4096, "goal_hold_rate": g_["TERMINAL_SUCCESS"] / 4096}
 
+        n_global = args.curriculum_envs * world
         # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
         # generations of all of them, or a level ends before most envs have finished an episode (Trainer default)
-        budget = max(args.curriculum_budget, 384 * args.envs * world)
+        budget = max(args.curriculum_budget, 384 * n_global)
         runs = []
-        for seed in (42, 1, 2, 3, 4, 5):  # tabular RL is seed-noisy (touchdown 85-95 % between seeds): six full curricula, each reported
+        for seed in CURRICULUM_SEEDS[:args.curriculum_seeds]:
             with tempfile.TemporaryDirectory() as d:
-                tr = Trainer(mode="paper", n_envs=args.envs * world, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=CURRICULUM_SYNC,
+                tr = Trainer(mode="paper", n_envs=n_global, device=dev_index, dtype=dtype, save_path=Path(d) / "run", chunk_steps=64, sync_period=CURRICULUM_SYNC,
                              max_num_episodes=budget, checkpoint_every=10**9, comm=comm, seed=seed, **CURRICULUM_KW)
                 t0 = time.perf_counter()
                 hist = tr.curriculum_training()
@@ -96,15 +158,22 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
                     runs.append({"seed": seed, "wall_to_stage4_s": hist[3]["wall_since_start_s"] if len(hist) > 3 else None, "wall_all_levels_s": total,
                                  "promoted_levels": sum(1 for h in hist if h["promoted"]),
                                  "levels": [{"level": h["level"], "promoted": h["promoted"], "exhausted": h["exhausted"], "episodes": h["episodes"],
-                                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"], "online_success_rate_at_handover": h["success_rate"]} for h in hist],
+                                             "agent_periods": h["agent_periods"], "wall_s": h["wall_s"],
+                                             "population_success_at_promotion": h["success_rate"] if h["promoted"] else None,
+                                             "online_success_rate_at_handover": h["success_rate"]} for h in hist],
                                  "stage4_greedy_4096_episodes": greedy(Path(d) / "run")})
                 tr._engine.close()
         if rank != 0:
             return None
         mean = lambda k: sum(r[k] for r in runs) / len(runs)
+        pops = [lv["population_success_at_promotion"] for r in runs for lv in r["levels"] if lv["promoted"]]
         return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper-mode MDP, reference update rule (quirks 0x60), one learning-rate step per agent period (Trainer default)",
-                "global_envs": args.envs * world, "episode_budget_per_level": budget, "sync_period": CURRICULUM_SYNC, "trainer_kw": CURRICULUM_KW,
+                "workload": f"BASELINE configs[3]{' share' if world > 1 or args.curriculum_envs == 32768 else ''}: {args.curriculum_envs} envs per GPU, full curriculum 0 -> 4",
+                "envs_per_gpu": args.curriculum_envs, "global_envs": n_global, "episode_budget_per_level": budget, "sync_period": CURRICULUM_SYNC, "trainer_kw": CURRICULUM_KW,
                 "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
+                "level0_promoted_per_seed": [bool(r["levels"][0]["promoted"]) for r in runs],
+                "population_success_at_promotion": {"min": min(pops) if pops else None, "mean": sum(pops) / len(pops) if pops else None,
+                                                    "note": "success rate of ALL envs' episodes over the chunks holding the most recent >= 100 episodes when the judged envs' deque passed 0.96 / 100"},
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},
@@ -112,16 +181,6 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
     except Exception as e:  # noqa: BLE001 - the throughput line must survive
         import traceback
         return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]} if rank == 0 else None
-
-
-# Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
-# (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
-# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl); 4 judged envs:
-# the deque sees the episodes of 4 envs (1 = the reference's own situation is the Trainer's default: same policy quality, a level
-# that sits at 93-95 % online success then needs ~2x the episodes until a 97 / 100 window comes by); 8 agent periods per launch
-# and table exchange every 8 (measured against 4 / 4: same policy quality, more levels promoted, profiles/r2_curriculum_p8.jsonl)
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 8}
-CURRICULUM_SYNC = 8
 
 
 def spawn_ranks(args) -> int:
@@ -173,33 +232,100 @@ def spawn_ranks(args) -> int:
     return 0
 
 
+def roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec_per_launch, n_launch, k_pairs_ms=None):
+    """`roofline` object of one measurement: achieved = algorithmic bytes per launch / average launch duration (HIP events on the engine's
+    stream around the back-to-back launches of the timed region); traffic = HBM bytes per launch from the committed PMC pass of the same
+    configuration AND the same kernel sources, else null."""
+    ab = algo_bytes(two_axis, randomize_platform)
+    ach = ab * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, note = None, None
+    prof, src = committed_profile("traffic")
+    key = flavour_key(envs, P, two_axis, randomize_platform, noise)
+    if prof is None:
+        note = src
+    elif key not in prof["configs"]:
+        note = f"profiles/{src} has no pass of configuration {key}"
+    else:
+        traffic = prof["configs"][key]["hbm_bytes_per_env_step"] * dec_per_launch
+        note = (f"profiles/{src} [{key}], same kernel sources ({prof['source_sha16']}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the "
+                "gfx950 correction), HBM bytes per env-step x env-steps per launch of this run")
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": note,
+           "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch, "agent_periods_per_launch": P,
+           "algorithmic_bytes_per_env_step": ab, "env_steps_per_launch": dec_per_launch,
+           "note": "the fused step is VALU-bound (~22 physics ticks per 328 B of state); HBM fraction reported as north_star asks"}
+    if k_pairs_ms is not None:
+        out["kernel_avg_ms_event_pairs"] = k_pairs_ms
+    return out
+
+
+def single_gpu_block(tag, what, envs, two_axis, randomize_platform, noise, dtype, dtype_name, P, eps, steps, warmup, device, block=0):
+    """One single-GPU throughput measurement with its own roofline (secondary blocks of the line: small_batch, large_batch)."""
+    from dql_multirotor_landing_amd.config import DqlConfig
+    from dql_multirotor_landing_amd.engine import Engine
+    cfg = DqlConfig(dtype=dtype, two_axis=two_axis, per_env_platform=randomize_platform, fold_per_step=1,
+                    noise_pos_sd=0.25 if noise else 0.0, noise_vel_sd=0.1 if noise else 0.0)
+    eng = Engine(cfg, envs, seed=42, device=device)
+    eng.set_option("block", block)
+    eng.set_option("periods_per_launch", P)
+    eng.train_steps(warmup, eps); eng.sync()
+    s0 = eng.stats(); eng.timer_start(); t0 = time.perf_counter()
+    eng.train_steps(steps, eps)
+    dev_ms = eng.timer_stop(); wall = time.perf_counter() - t0
+    s1 = eng.stats()
+    eng.close()
+    dec = s1["decisions"] - s0["decisions"]
+    n_launch = -(-steps // P)
+    k_ms = dev_ms / n_launch
+    out = {"workload": f"{tag}: {what}", "envs": envs, "value": dec / wall, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
+           "device_ms_per_step": dev_ms / steps, "periods_per_launch": P,
+           "roofline": roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec / n_launch, n_launch)}
+    v = valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, steps / n_launch)
+    if v:
+        out["valu_roofline"] = v
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--preroll", type=int, default=512,
+                    help="untimed agent periods run on the engine BEFORE the W warm-up periods: a GPU that was idle while the process started runs its first "
+                         "millisecond at idle clocks, and W = 5 periods (0.2 ms) do not reach the sustained clock (measured: 47.8 vs 35.3 us per period); reported in the line")
+    ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4], help="BASELINE.json configs[k] preset of the throughput leg (per-GPU share); default 4 at every N")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (weak scaling); overrides the preset")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eps", type=float, default=1.0)
-    ap.add_argument("--sync-period", type=int, default=32, help="agent periods between table exchanges of the headline run (N > 1); sync_period 2 is reported next to it")
+    ap.add_argument("--sync-period", type=int, default=8,
+                    help="agent periods between table exchanges (N > 1).  Default 8 = periods per launch: the smallest window that costs no extra launch boundary; "
+                         "a rank then acts on tables that miss at most the other ranks' last 8 + 8 (one-launch fold delay) + 8 (window in flight) = 24 periods")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--periods-per-launch", type=int, default=8, help="agent periods per kernel launch (engine option; 1 = one launch per period)")
-    ap.add_argument("--two-axis", type=int, default=0, help="1 = BASELINE configs[2] flavour: joint x+y MDP")
-    ap.add_argument("--randomize-platform", type=int, default=0, help="1 = per-env platform amplitude / speed (BASELINE configs[4] flavour)")
-    ap.add_argument("--noise", type=int, default=0, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (BASELINE configs[4] flavour)")
+    ap.add_argument("--two-axis", type=int, default=None, help="1 = joint x+y MDP (overrides the preset)")
+    ap.add_argument("--randomize-platform", type=int, default=None, help="1 = per-env platform amplitude / speed (overrides the preset)")
+    ap.add_argument("--noise", type=int, default=None, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (overrides the preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"],
                     help="table exchange between ranks: RCCL all-reduce (default) or the one-shot peer-to-peer push + local sum (dql_p2p_*: opt-in, "
                          "functionally tested with ranks sharing one GPU, not yet measured across GPUs)")
     ap.add_argument("--exchange-rehearsal", action="store_true",
                     help="one rank, but through every code path of a multi-rank run (RCCL communicator of world size 1, window exchange, sync legs, sharded curriculum): a rehearsal on a 1-GPU box, flagged in the line, not a measurement")
-    ap.add_argument("--cpu-steps", type=int, default=1000, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
-    ap.add_argument("--large-envs", type=int, default=1048576, help="extra single-GPU measurement at a chip-filling batch (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=600, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
+    ap.add_argument("--small-envs", type=int, default=4096, help="secondary single-GPU block at BASELINE configs[1] (0 = skip)")
+    ap.add_argument("--large-envs", type=int, default=1048576, help="secondary single-GPU block at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
-    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 64 per env")
+    ap.add_argument("--curriculum-envs", type=int, default=32768, help="envs per GPU of the curriculum leg (BASELINE configs[3]: 262 144 / 8)")
+    ap.add_argument("--curriculum-seeds", type=int, default=6, help="how many of the six seeds to run")
+    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 384 per env")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    pre = PRESETS[args.config]
+    for k in ("envs", "two_axis", "randomize_platform", "noise"):
+        if getattr(args, k) is None:
+            setattr(args, k, pre[k])
+    custom = any(getattr(args, k) != pre[k] for k in ("envs", "two_axis", "randomize_platform", "noise"))
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # by torch.distributed.run, or by spawn_ranks below
     if not launched and args.gpus > 1:
@@ -234,8 +360,9 @@ def main():
 
     # fold_per_step = 1: the Trainer's default table update (one learning-rate step per agent period towards the period's mean
     # target) — the throughput leg runs the update rule the curriculum leg trains with
-    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, two_axis=args.two_axis, per_env_platform=args.randomize_platform, fold_per_step=1,
-                    noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
+    cfg_kw = dict(two_axis=args.two_axis, per_env_platform=args.randomize_platform, fold_per_step=1,
+                  noise_pos_sd=0.25 if args.noise else 0.0, noise_vel_sd=0.1 if args.noise else 0.0)
+    cfg = DqlConfig(dtype=dtype, working_curriculum_step=0, **cfg_kw)
     eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
     # any --steps K works: the engine cuts K periods into launches of at most P (the last one shorter)
@@ -277,23 +404,29 @@ def main():
             wall = float(comm.all_reduce_max([wall])[0]); dec = int(comm.all_reduce_sum([float(dec)])[0])
         return wall, dec, dev_ms
 
-    wall, decisions, dev_ms = timed(args.sync_period, args.steps, args.warmup)
+    # pre-roll + W warm-up periods, all untimed, all on the run's own table schedule (exchanges included with several ranks)
+    wall, decisions, dev_ms = timed(args.sync_period, args.steps, args.preroll + args.warmup)
     sync_info = None
     if multi:
         # the exchange's price: same region without exchanges (one window, folded after the clock stops: NOT a valid training
         # schedule, a yardstick), and at sync_period 2 (the regime in which the run does not depend on the number of ranks)
         w_none, d_none, _ = timed(args.steps + args.warmup + 1, args.steps, 0, final_exchange=False)
-        w_two, d_two, _ = timed(2, args.steps, 0)
+        others = {}
+        for sp in (2, 8, 32):
+            if sp != args.sync_period:
+                w_sp, d_sp, _ = timed(sp, args.steps, 0)
+                others[f"sync_period_{sp}"] = {"value": d_sp / w_sp, "ms_per_step": w_sp * 1e3 / args.steps, "sync_ms_per_step": (w_sp - w_none) * 1e3 / args.steps}
         eng.kernel_timer(True)
         r2 = ShardedRunner(eng, reducer, sync_period=args.sync_period); r2.train_steps(4 * args.sync_period, args.eps); r2.sync()
         sync_dev_ms, n_sync = eng.sync_time_ms()
         eng.kernel_timer(False)
         sync_info = {"sync_period": args.sync_period, "ms_per_step": wall * 1e3 / args.steps, "ms_per_step_no_exchange": w_none * 1e3 / args.steps,
                      "sync_ms_per_step": (wall - w_none) * 1e3 / args.steps, "exchange_device_ms": sync_dev_ms, "exchanges_timed": n_sync,
+                     "staleness_bound_periods": args.sync_period + 2 * max(args.sync_period, args.periods_per_launch),
+                     "staleness_note": "a rank acts on tables that hold every rank's updates older than this many agent periods: the window in flight, the launch whose accumulators are being folded, and the launch in progress",
                      "exchange": ("flush + push of 11 340 int64 words into every rank's exchange buffer (HIP IPC, uncached) + flags + local sum + fold, on the engine's stream"
                                   if args.exchange == "p2p" else "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream"),
-                     "p2p_failed": eng.p2p_failed() if args.exchange == "p2p" else None,
-                     "sync_period_2": {"value": d_two / w_two, "ms_per_step": w_two * 1e3 / args.steps, "sync_ms_per_step": (w_two - w_none) * 1e3 / args.steps}}
+                     "p2p_failed": eng.p2p_failed() if args.exchange == "p2p" else None, **others}
 
     # Average launch duration of the fused step kernel, HIP events on the engine's stream.  One rank: the step kernel is the
     # only kernel between the two events of the timed region (K launches back to back), so duration = region / K — the figure
@@ -312,78 +445,67 @@ def main():
     k_ms = dev_ms / n_launch if not multi else k_pairs_ms
     if not multi:
         dec_per_launch = decisions / n_launch  # average over the launches of the timed region (kernel_avg_ms is their average duration)
+    eng.close()
 
     curriculum = None
-    if not args.no_curriculum and not args.two_axis:
+    if not args.no_curriculum:
         curriculum = curriculum_leg(args, comm, world, rank, dev_index, dtype)
 
     if rank == 0:
         value = decisions / wall
-        traffic, traffic_note = None, "no committed PMC pass for this envs/block configuration"
-        tf = ROOT / "profiles" / "r2_traffic.json"
-        if tf.exists():
-            t = json.loads(tf.read_text())["configs"].get(f"{args.envs}_p{P}")
-            if t:
-                traffic = t["hbm_bytes_per_env_step"] * dec_per_launch
-                traffic_note = ("profiles/r2_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 correction), HBM bytes "
-                                "per env-step of the same envs / periods-per-launch configuration x env-steps per launch of this run")
-        algo_b = ALGO_BYTES_PER_ENV_STEP_2AXIS if args.two_axis else ALGO_BYTES_PER_ENV_STEP
-        ach = algo_b * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        ab = algo_bytes(args.two_axis, args.randomize_platform)
+        tag = (pre["tag"] if not custom else f"custom (preset {pre['tag']} with overrides)")
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "preroll_steps": args.preroll, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[{2 if args.two_axis else 1}]: {args.envs} vectorised envs per GPU, {'joint x+y 2-axis' if args.two_axis else 'x-axis'} MDP, curriculum step 0, eps {args.eps}, "
-                                   f"rpm platform r=2 m omega=0.8 rad/s, ONE fused kernel per {args.periods_per_launch} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
-                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if multi else 1, "exchange_rehearsal": bool(args.exchange_rehearsal),
-                       "periods_per_launch": args.periods_per_launch, "fold_per_step": 1,
+            "config": {"workload": f"{tag}: " + (pre["what"] if not custom else f"{args.envs} envs per GPU, two_axis {args.two_axis}, per-env platform {args.randomize_platform}, noise {args.noise}") +
+                                   f"; eps {args.eps}, ONE fused kernel per {P} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
+                       "baseline_config": args.config, "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if multi else 1,
+                       "exchange_rehearsal": bool(args.exchange_rehearsal), "periods_per_launch": P, "fold_per_step": 1,
                        "parallelism": f"env-shard x{world}" + ((", one-shot peer-to-peer window exchange (libdql_hip.so, HIP IPC)" if args.exchange == "p2p" else ", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)") if multi else ""), "block": args.block,
-                       "randomize_platform": args.randomize_platform, "noise": args.noise},
+                       "two_axis": args.two_axis, "randomize_platform": args.randomize_platform, "noise": args.noise, "algorithmic_bytes_per_env_step": ab,
+                       "library_source_sha16": lib_source_sha16()},
             "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch if not multi else k_n, "agent_periods_per_launch": P,
-                         "kernel_avg_ms_event_pairs": k_pairs_ms,
-                         "algorithmic_bytes_per_env_step": algo_b, "env_steps_per_launch": dec_per_launch,
-                         "note": "the fused step is VALU-bound (~22 physics ticks per 400 B of state); HBM fraction reported as north_star asks"},
-            "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92, "source": "BASELINE.md section 2 (artefact-derived, not re-measured)"},
+            "roofline": roofline_block(args.envs, P, args.two_axis, args.randomize_platform, args.noise, k_ms, dec_per_launch, n_launch if not multi else k_n, k_pairs_ms),
+            "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92,
+                                 "reference_python_mdp+agent_us_per_step": 69.6, "reference_python_mdp+agent_steps_per_s": 14.4e3,
+                                 "source": "BASELINE.md section 2 (artefact-derived / measured in the survey container on 1 core; not re-measurable on the GPU box)"},
         }
         if sync_info:
             out["sync"] = sync_info
             out["sync_ms_per_step"] = sync_info["sync_ms_per_step"]
-        valu = valu_roofline(args, k_ms, args.steps / n_launch if not multi else P)
+        valu = valu_roofline(args.envs, P, args.two_axis, args.randomize_platform, args.noise, args.dtype, k_ms, args.steps / n_launch if not multi else P)
         if valu:
             out["valu_roofline"] = valu
-        if not multi and args.envs != args.large_envs and args.large_envs > 0:
-            # same kernel at a batch that fills the chip (not the headline config; reported for the roofline discussion)
-            big = Engine(DqlConfig(dtype=dtype, two_axis=args.two_axis, fold_per_step=1), args.large_envs, seed=42)
-            big.set_option("periods_per_launch", P)
-            big.train_steps(5 * P, args.eps); big.sync()
-            b0 = big.stats(); big.timer_start(); big.train_steps(40 * P, args.eps); b_ms = big.timer_stop(); b1 = big.stats()
-            b_dec = b1["decisions"] - b0["decisions"]
-            out["large_batch"] = {"envs": args.large_envs, "value": b_dec / (b_ms * 1e-3), "unit": "env-steps/s", "ms_per_step": b_ms / (40 * P), "periods_per_launch": P,
-                                  "hbm_frac_algorithmic": algo_b * b_dec / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-            big.close()
+        if not multi:
+            # secondary single-GPU blocks, each with its own roofline from stream events of THIS run
+            if args.small_envs > 0 and not (args.envs == args.small_envs and not custom and args.config == 1):
+                p1 = PRESETS[1]
+                out["small_batch"] = single_gpu_block(p1["tag"], p1["what"], args.small_envs, 0, 0, 0, dtype, args.dtype, P, args.eps, max(args.steps, 400), max(args.warmup, 40), dev_index)
+            if args.large_envs > 0 and args.envs != args.large_envs:
+                out["large_batch"] = single_gpu_block("chip-filling batch (= configs[4] on ONE GPU)", "1 048 576 envs, per-env randomised platforms + observation noise" if args.large_envs == 1048576 else f"{args.large_envs} envs, per-env randomised platforms + observation noise",
+                                                      args.large_envs, 0, 1, 1, dtype, args.dtype, P, args.eps, 40 * P, 5 * P, dev_index)
         if curriculum is not None:
             out["curriculum"] = curriculum
-            if "error" not in curriculum:  # the two figures the stage-4 check is read from, at the top level
+            if "error" not in curriculum:  # the figures the stage-4 check is read from, at the top level
                 out["promoted_levels"] = curriculum["promoted_levels_per_seed"]
                 out["goal_hold_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["goal_hold_rate"]
                 out["touchdown_rate"] = curriculum["stage4_greedy_4096_episodes"]["trained_mean"]["touchdown_rate"]
                 out["wall_to_stage4_s"] = curriculum["wall_to_stage4_s"]
         if not args.no_cpu_baseline and not multi:
-            out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, args.two_axis)
+            out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, {k: v for k, v in cfg_kw.items()})
         print(json.dumps(out), flush=True)
-    eng.close()
     if comm:
         comm.barrier()
         comm.close()
 
 
-def valu_roofline(args, k_ms, periods_per_launch_avg):
+def valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, periods_per_launch_avg):
     """The roof that actually binds: wave64 VALU instructions through 1024 SIMDs, with the instruction count per env wave from the
-    committed PMC pass (profiles/r2_pmc_sq_summary.json) and issue costs per instruction FORM from the asm micro benchmarks
-    (tools/micro/pk_variants.hip, valu_forms.hip -> profiles/r2_pk_variants.jsonl, r2_valu_forms.jsonl; placement verified from HW_ID).
-    What those found on this chip (2.3-2.4 GHz shader clock):
+    committed PMC pass of THIS library's sources (profiles/r*_pmc_sq_summary.json, stamped) and issue costs per instruction FORM from the
+    asm micro benchmarks (tools/micro/pk_variants.hip, valu_forms.hip -> profiles/r2_pk_variants.jsonl, r2_valu_forms.jsonl; placement
+    verified from HW_ID).  What those found on this chip (2.3-2.4 GHz shader clock):
       >= 2 waves per SIMD:  v_fma / v_mul / v_add / v_mov / v_and with VGPR or literal sources 0.95-1.25 ns (the guide's "2 cycles" row,
                             2.3-3 cycles measured); ANY SGPR source operand 1.8-1.95 ns; compares, selects, min / max / med3, conversions,
                             integer ops 1.7-1.9 ns (4 cycles); v_pk_*_f32 1.9-2.1 ns (two operations: no gain); v_sqrt / v_rcp 3.5 ns
@@ -391,27 +513,28 @@ def valu_roofline(args, k_ms, periods_per_launch_avg):
                             packed tick of small batches lives on), v_sqrt / v_rcp 3.6-3.9 ns
     Three prices per launch: every instruction at the full-rate form's cost ("all_full_rate": no kernel with compares and selects can
     reach it), the kernel's own mix of forms in the tick loop (tools/isa_sections.py, "own_mix"), and MI355X_MICROARCH.md's table row."""
-    if args.two_axis or args.dtype != "f32":
+    if two_axis or dtype_name != "f32":
         return None
-    pf = ROOT / "profiles" / "r2_pmc_sq_summary.json"
-    if not pf.exists():
-        return None
-    pm = json.loads(pf.read_text())
-    P = args.periods_per_launch
-    # instruction count per env wave per PERIOD: the pass of this env count (any periods per launch; the count per period moves by
-    # < 2 % with it), else the nearest committed size
-    cands = sorted(pm, key=lambda k: (abs(int(k.split("_p")[0]) - args.envs), abs(int(k.split("_p")[1]) - P)))
-    ref = pm[cands[0]] if cands else None
-    if not ref:
-        return None
+    pm, src = committed_profile("pmc_sq_summary")
+    if pm is None:
+        return {"note": src}
+    passes = pm["configs"]
+    key = flavour_key(envs, P, two_axis, randomize_platform, noise)
+    if key not in passes:  # the pass of this env count and flavour at another periods-per-launch (the count per period moves by < 2 % with it)
+        suffix = key.split(f"_p{P}", 1)[1]
+        same = [k for k in passes if k.split("_p")[0] == str(envs) and k.split("_p", 1)[1].lstrip("0123456789") == suffix]
+        if not same:
+            return {"note": f"profiles/{src} has no pass of configuration {key}"}
+        key = same[0]
+    ref = passes[key]
     valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * periods_per_launch_avg  # per (average) launch of the timed region
-    waves = (args.envs + 63) // 64
+    waves = (envs + 63) // 64
     lone = waves <= 1024
-    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
-           "source": f"profiles/{pf.name} (instruction count), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
-    # own mix per tick (tools/isa_sections.py x the table above): plain loop 250 full-rate + 28 four-cycle + 88 SGPR-operand + 4 sqrt of 370
-    # = 1.39 ns; literal-constant loop (> 196 608 envs) 304 + 33 + 18 + 4 of 359 = 1.27 ns; packed lone wave 2.3 ns
-    mix = 2.3 if lone else (1.27 if args.envs > 196608 else 1.39)
+    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "valu_instr_per_env_wave_per_period": ref["SQ_INSTS_VALU_per_env_wave_per_period"],
+           "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
+           "source": f"profiles/{src} [{key}] (instruction count, same kernel sources), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
+    # own mix per tick (tools/isa_sections.py x the table above): plain loop 1.39 ns; literal-constant loop (> 196 608 envs) 1.27 ns; packed lone wave 2.3 ns
+    mix = 2.3 if lone else (1.27 if envs > 196608 else 1.39)
     prices = (("all_full_rate", 2.2 if lone else 1.15), ("own_mix", mix), ("guide_table", (4 if lone else 2) / 2.4))
     for tag, ns in prices:
         floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)

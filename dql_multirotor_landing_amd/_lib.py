@@ -11,7 +11,7 @@ from .config import DqlConfigC, N_CHECK_CODES
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
-OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL = 0, -1, -2, -3, -4, -5
+OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL, EPEER = 0, -1, -2, -3, -4, -5, -6
 ABI_VERSION = 3
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -42,6 +42,7 @@ SYMBOLS = {
     "dql_reset": (C.c_int, [_vp, _vp]),
     "dql_step": (C.c_int, [_vp, _vp]),
     "dql_step_dev": (C.c_int, [_vp, _vp]),
+    "dql_step_outputs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dql_train_steps": (C.c_int, [_vp, _i32, _dbl]),
     "dql_eval_steps": (C.c_int, [_vp, _i32]),
     "dql_get_states": (C.c_int, [_vp, _vp, _vp]),
@@ -82,7 +83,10 @@ SYMBOLS = {
     "dql_allreduce_window": (C.c_int, [_vp]),
     "dql_p2p_create": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "dql_p2p_connect": (C.c_int, [_vp, _vp]),
+    "dql_p2p_connect_local": (C.c_int, [_vp, _vp]),
     "dql_p2p_exchange_window": (C.c_int, [_vp]),
+    "dql_p2p_push_window": (C.c_int, [_vp]),
+    "dql_p2p_wait_window": (C.c_int, [_vp]),
     "dql_p2p_status": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "dql_sync_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
     "dql_stats_get": (C.c_int, [_vp, C.POINTER(DqlStatsC)]),
@@ -100,6 +104,12 @@ SYMBOLS = {
     "dql_manager_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _u64, _vp]),
     "dql_plant_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "dql_place": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
+    "dql_agent_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "dql_agent_destroy": (C.c_int, [_vp]),
+    "dql_agent_set_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "dql_agent_get_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "dql_agent_predict_resident": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "dql_agent_update_resident": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp, _vp, _vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp]),

@@ -9,7 +9,10 @@ No PyTorch: `libdql_hip.so` loads librccl itself.  The only thing ranks need out
 All ranks of a node share their parent (torch.distributed.run's agent, or `bench.py --gpus N` itself), and (pid, start
 time) of a live process is unique, so a file left behind by an earlier job can never be mistaken for this one's; `<n>`
 counts the communicators a process has created (every rank creates them in the same order).  Rank 0 writes the file
-atomically (temp + rename) and removes it when the communicator is closed.
+atomically (temp + rename) and removes it when the communicator is closed.  An explicit $DQL_COMM_ID_FILE has no such nonce
+in its name, so every bootstrap file also carries one inside — a 16-byte header (magic, MASTER_PORT, WORLD_SIZE) — and a reader
+only accepts a file with its own job's header that is not older than the reader itself (minus a minute of slack for ranks that
+start late): what a killed job left behind is polled past, not used.
 
 Launch contract (same variables torch.distributed.run exports): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.
 """
@@ -29,6 +32,27 @@ from . import _lib
 
 _created = 0          # communicators created by this process so far
 _env_comm = None      # the job's communicator (from_env), shared by everything in this process
+_T_START = time.time()  # this process's start, near enough: bootstrap files older than this (minus _STALE_SLACK_S) are leftovers
+_STALE_SLACK_S = 60.0
+
+
+def _header(world: int) -> bytes:
+    port = int(os.environ.get("MASTER_PORT", "0") or 0) & 0xFFFFFFFF
+    return b"DQLC" + port.to_bytes(4, "little") + int(world).to_bytes(4, "little") + b"\0\0\0\0"
+
+
+def _read_fresh(f: Path, world: int, n_payload: int) -> Optional[bytes]:
+    """payload of bootstrap file `f` if it is this job's (header) and not a leftover (age), else None"""
+    try:
+        if f.stat().st_mtime < _T_START - _STALE_SLACK_S:
+            return None
+        b = f.read_bytes()
+    except OSError:
+        return None
+    h = _header(world)
+    if len(b) != len(h) + n_payload or b[:len(h)] != h:
+        return None
+    return b[len(h):]
 
 
 def _parent_token() -> str:
@@ -54,29 +78,30 @@ def gather_via_files(tag: str, rank: int, world: int, payload: bytes, timeout_s:
     on a collective library.  Returns the payloads in rank order; every rank removes its own file once all are read."""
     base = id_file_path(0)
     mine = base.with_name(f"{base.stem}.{tag}.{rank}.bin")
+    done = base.with_name(f"{base.stem}.{tag}.{rank}.done")
+    try:  # a marker of an earlier job under the same explicit name must not tell a peer that THIS rank has read everything
+        done.unlink()
+    except OSError:
+        pass
     tmp = mine.with_suffix(f".{os.getpid()}.tmp")
-    tmp.write_bytes(payload)
+    tmp.write_bytes(_header(world) + payload)
     os.replace(tmp, mine)
     out, t0 = [], time.monotonic()
     for r in range(world):
         f = base.with_name(f"{base.stem}.{tag}.{r}.bin")
         while True:
-            try:
-                b = f.read_bytes()
-                if len(b) == len(payload):
-                    break
-            except OSError:
-                pass
+            b = _read_fresh(f, world, len(payload))
+            if b is not None:
+                break
             if time.monotonic() - t0 > timeout_s:
                 raise RuntimeError(f"rank {rank}: nothing from rank {r} after {timeout_s:.0f} s ({f})")
             time.sleep(0.01)
         out.append(b)
     # a second round of marker files: nobody deletes what a slower rank has not read yet
-    done = base.with_name(f"{base.stem}.{tag}.{rank}.done")
-    done.write_bytes(b"1")
+    done.write_bytes(_header(world))
     for r in range(world):
         d = base.with_name(f"{base.stem}.{tag}.{r}.done")
-        while not d.exists():
+        while _read_fresh(d, world, 0) is None:
             if time.monotonic() - t0 > timeout_s:
                 raise RuntimeError(f"rank {rank}: rank {r} never finished reading ({d})")
             time.sleep(0.01)
@@ -113,17 +138,14 @@ class RcclComm:
             _lib.check(self.lib.dql_comm_unique_id(uid))
             if self.world > 1:
                 tmp = self._id_file.with_suffix(f".{os.getpid()}.tmp")
-                tmp.write_bytes(bytes(uid))
+                tmp.write_bytes(_header(self.world) + bytes(uid))
                 os.replace(tmp, self._id_file)
         else:
             t0 = time.monotonic()
             while True:
-                try:
-                    b = self._id_file.read_bytes()
-                    if len(b) == _lib.COMM_ID_BYTES:
-                        break
-                except OSError:
-                    pass
+                b = _read_fresh(self._id_file, self.world, _lib.COMM_ID_BYTES)
+                if b is not None:
+                    break
                 if time.monotonic() - t0 > timeout_s:
                     raise RuntimeError(f"rank {self.rank}: no unique id from rank 0 after {timeout_s:.0f} s ({self._id_file})")
                 time.sleep(0.02)

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,7 +42,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 #define CHECK_CTX(ctx) do { if (!(ctx)) return fail(DQL_EINVAL, "null context"); } while (0)
 
-struct StatsDev { unsigned long long decisions, episodes, by_code[DQL_N_CHECK_CODES]; long long reward_fx; unsigned long long agent_steps; };
+struct StatsDev { unsigned long long decisions, episodes, by_code[DQL_N_CHECK_CODES]; long long reward_fx; unsigned long long agent_steps, bad_actions; };
 
 // ---------------------------------------------------------------------------------------------
 // host -> device constants
@@ -306,6 +307,10 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     dec = 0; don = 0; rfx = 0; goal = false;
     if (i < a.n) {
       const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
+      if (a.mode == MODE_EXTERNAL) {  // the caller's actions are checked here, not by a host loop (dql_step): ax | ay << 2, both in 0..2
+        const int ax = ext & 3, ay = (ext >> 2) & 3;
+        if (ax > 2 || ay > 2 || (ext >> 4) || (!a.c.two_axis && ay != 0 && ay != 2)) atomicAdd(&a.stats->bad_actions, 1ull);
+      }
       const StepOut o = agent_period<TICK>(a.c, tc, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
@@ -500,22 +505,54 @@ __global__ void k_predict(const double* qa, const double* qb, const int* idx, lo
   if (i < n) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
 }
 // ordered replay of DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146): inherently sequential -> one lane
+// one DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146); returns the updated cell's new value
+DQL_DEV double agent_update_one(double* qa, double* qb, double* count, int sa, int ns, double alpha, double gamma, double reward, uint32_t quirks, bool coin, bool done) {
+  const bool dbl = !(quirks & DQL_Q_UPDATE_TABLE_A_ONLY);  // Double Q-learning: coin picks the table, the other one values (B1/B2 off)
+  count[sa] += 1;
+  const bool sel_b = dbl && coin;
+  double* qsel = sel_b ? qb : qa;
+  const double* qval = dbl ? (sel_b ? qa : qb) : qa;
+  const double q0 = qsel[ns * 3], q1 = qsel[ns * 3 + 1], q2 = qsel[ns * 3 + 2];
+  const int b = argmax3(q0, q1, q2);
+  const double best = qval[ns * 3 + b];
+  const int mask = (quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) ? (idx_pos(sa / 3) != idx_pos(ns)) : !done;
+  const double loss = alpha * (reward + (gamma * best) * (double)mask - qsel[sa]);
+  qsel[sa] += loss;
+  return qsel[sa];
+}
 __global__ void k_update_seq(double* qa, double* qb, double* count, const int* sa, const int* ns, const double* alpha, double gamma,
                              const double* reward, long long n, uint32_t quirks, const uint8_t* coin, const uint8_t* done) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const bool dbl = !(quirks & DQL_Q_UPDATE_TABLE_A_ONLY);  // Double Q-learning: coin picks the table, the other one values (B1/B2 off)
+  for (long long i = 0; i < n; ++i) agent_update_one(qa, qb, count, sa[i], ns[i], alpha[i], gamma, reward[i], quirks, coin && coin[i] != 0, done && done[i] != 0);
+}
+// resident agent (dql_agent_*): arguments and results in pinned host memory, read and written by the kernel itself
+struct AgentUpdIn { int sa, ns; double alpha, reward; int coin, done; };
+struct AgentUpdOut { double q_new, count_new; };
+__global__ void k_update_resident(double* qa, double* qb, double* count, const AgentUpdIn* in, AgentUpdOut* out, long long n, double gamma, uint32_t quirks) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (long long i = 0; i < n; ++i) {
-    count[sa[i]] += 1;
-    const bool sel_b = dbl && coin[i] != 0;
-    double* qsel = sel_b ? qb : qa;
-    const double* qval = dbl ? (sel_b ? qa : qb) : qa;
-    const double q0 = qsel[ns[i] * 3], q1 = qsel[ns[i] * 3 + 1], q2 = qsel[ns[i] * 3 + 2];
-    const int b = argmax3(q0, q1, q2);
-    const double best = qval[ns[i] * 3 + b];
-    const int mask = (quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) ? (idx_pos(sa[i] / 3) != idx_pos(ns[i])) : !done[i];
-    const double loss = alpha[i] * (reward[i] + (gamma * best) * (double)mask - qsel[sa[i]]);
-    qsel[sa[i]] += loss;
+    const AgentUpdIn u = in[i];
+    out[i].q_new = agent_update_one(qa, qb, count, u.sa, u.ns, u.alpha, gamma, u.reward, quirks, u.coin != 0, u.done != 0);
+    out[i].count_new = count[u.sa];
   }
+  __threadfence_system();
+}
+__global__ void k_predict_resident(const double* qa, const double* qb, const int* idx, long long n, uint8_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
+  __threadfence_system();
+}
+// what TrainingLandingEnv.step returns, gathered per env into pinned host memory (dql_step_outputs)
+struct StepOutRec { int idx_x, idx_y, step_count, code_flags; double reward, cum; };
+template <typename T> __global__ void k_step_outputs(const Quad<T>* __restrict__ sr, const int4* __restrict__ si, long long n, StepOutRec* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 iv = si[i];
+  StepOutRec r;
+  r.idx_x = iv.x; r.idx_y = iv.y; r.step_count = iv.z & 0xffff; r.code_flags = iv.w & 0xffff;
+  r.reward = (double)sr[14 * n + i].a; r.cum = (double)sr[10 * n + i].b;
+  out[i] = r;
+  __threadfence_system();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,23 +579,28 @@ __global__ void k_p2p_signal(P2PPushArgs a, unsigned long long seq) {
   const int r = threadIdx.x;
   if (r < a.world) __hip_atomic_store(&p2p_flags(a.peer[r], a.world, a.parity)[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_p2p_wait_sum(unsigned long long* mine, long long* window, int world, int parity, unsigned long long seq, int* status, long long spin_limit) {
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
-    int good = 1;
-    const unsigned long long* f = p2p_flags(mine, world, parity);
-    for (int r = 0; r < world && good; ++r) {
-      long long spins = 0;  // every wave reaches an exit: spin_limit polls (default 10 M, ~10 s), then the exchange is reported as failed
-      while (__hip_atomic_load(&f[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        if (++spins > spin_limit) { good = 0; break; }
-        __builtin_amdgcn_s_sleep(8);
-      }
+// ONE waiter per exchange (a single wave; lane r polls peer r's flag): the verdict it leaves — verdict[0] = the last exchange every
+// peer showed up for, verdict[1] = the first exchange that was given up on (0 = none) — is what the sum kernel obeys, so a window is
+// either the full sum or untouched, never summed by some workgroups and not by others
+__global__ void k_p2p_wait(const unsigned long long* mine, int world, int parity, unsigned long long seq, unsigned long long* verdict, long long spin_limit) {
+  const int r = threadIdx.x;
+  bool good = true;
+  if (r < world) {
+    const unsigned long long* f = p2p_flags(const_cast<unsigned long long*>(mine), world, parity);
+    long long spins = 0;  // every lane reaches an exit: spin_limit polls, then the exchange is reported as failed
+    while (__hip_atomic_load(&f[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (++spins > spin_limit) { good = false; break; }
+      __builtin_amdgcn_s_sleep(8);
     }
-    if (!good) atomicExch(status, 1);
-    ok = good;
   }
-  __syncthreads();
-  if (!ok) return;
+  const bool all_good = __ballot(!good) == 0ull;
+  if (r == 0) {
+    if (all_good) verdict[0] = seq;
+    else if (verdict[1] == 0ull) verdict[1] = seq;
+  }
+}
+__global__ void k_p2p_sum(unsigned long long* mine, long long* window, int world, int parity, unsigned long long seq, const unsigned long long* verdict) {
+  if (verdict[0] != seq) return;  // given up on: the window stays this rank's own (wave-uniform, whole grid)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= DQL_ACC_LEN) return;
   unsigned long long sum = 0;
@@ -604,6 +646,9 @@ struct dql_ctx {
   bool lit_ok = false;  // float32 and the tick constants are bit-identical to dql_refk.inc
   unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
   int elog_cap = 0, elog_n = 0;
+  uint8_t* h_actions = nullptr;  // pinned staging of dql_step's host actions (their copy to the device is asynchronous)
+  hipEvent_t ev_actions = nullptr; bool actions_in_flight = false;
+  void* h_out = nullptr; void* h_out_dev = nullptr;  // pinned, device-visible: StepOutRec[n] of dql_step_outputs
   uint8_t* d_mask = nullptr;     // reset mask staging (dql_reset), allocated on first use
   const uint8_t* ext_actions = nullptr;  // caller-owned device actions of the next external step (dql_step_dev), else d_actions
   long long window_launches = 0; // training launches whose accumulators the window holds (windowed mode)
@@ -614,12 +659,23 @@ struct dql_ctx {
   unsigned long long* p2p_buf = nullptr;
   unsigned long long* p2p_peer[DQL_P2P_MAX_RANKS] = {nullptr};
   bool p2p_opened[DQL_P2P_MAX_RANKS] = {false};
-  int* p2p_status = nullptr;  // device word: 0 = every wait so far saw its peers, 1 = a wait gave up
+  unsigned long long* p2p_status = nullptr;  // device verdict[2]: the last exchange every peer showed up for, the first exchange given up on (0 = none)
   unsigned long long p2p_seq = 0;
-  long long p2p_spin_limit = 10000000ll;  // option "p2p_spin_limit"
+  bool p2p_pushed = false;  // a push is enqueued whose wait is not (dql_p2p_push_window / dql_p2p_wait_window)
+  long long p2p_spin_limit = 60000000ll;  // option "p2p_spin_limit": a peer may be busy with a checkpoint or an evaluation for a while
   std::vector<hipEvent_t> sev;   // event pairs around the exchanges while the kernel timer is armed
 };
 
+// first exchange of the peer-to-peer path that gave up on a missing peer (0 = none); synchronises the stream
+static int p2p_failed_seq(dql_ctx* x, unsigned long long* seq_out) {
+  *seq_out = 0;
+  if (!x->p2p_status) return DQL_OK;
+  unsigned long long v[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(v, x->p2p_status, sizeof(v), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  *seq_out = v[1];
+  return DQL_OK;
+}
 static int check_config(const dql_config* c) {
   if (!c) return fail(DQL_EINVAL, "null config");
   if (c->working_curriculum_step < 0 || c->working_curriculum_step >= DQL_MAX_LEVELS) return fail(DQL_EINVAL, "working_curriculum_step must be in 0..4");
@@ -716,12 +772,14 @@ template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps
 static int launch_period(dql_ctx* x, int mode, double eps, int n_periods = 1) {
   if (x->elog && x->elog_n + n_periods > x->elog_cap) return fail(DQL_ESTATE, "episode log full: read it with dql_episode_log_read before stepping on");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (x->kernel_timer) {
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  if (x->kernel_timer) {  // the pair belongs to the context from its creation on (dql_kernel_timer / dql_destroy free it), whatever fails below
+    HIP_TRY(hipEventCreate(&e0)); x->kev.push_back(e0);
+    if (hipEventCreate(&e1) != hipSuccess) { x->kev.pop_back(); (void)hipEventDestroy(e0); return fail(DQL_EHIP, "hipEventCreate failed"); }
+    x->kev.push_back(e1);
     HIP_TRY(hipEventRecord(e0, x->stream));
   }
   if (x->dtype == DQL_F32) launch_step_b<float>(x, mode, eps, n_periods); else launch_step_b<double>(x, mode, eps, n_periods);
-  if (x->kernel_timer) { HIP_TRY(hipEventRecord(e1, x->stream)); x->kev.push_back(e0); x->kev.push_back(e1); }
+  if (x->kernel_timer) HIP_TRY(hipEventRecord(e1, x->stream));
   HIP_TRY(hipGetLastError());
   if (x->elog) x->elog_n += n_periods;
   x->pending = (mode == MODE_TRAIN);  // this launch's accumulators wait for the next launch's writer blocks (or a flush)
@@ -902,6 +960,9 @@ int dql_destroy(dql_ctx* x) {
   for (int r = 0; r < DQL_P2P_MAX_RANKS; ++r) if (x->p2p_opened[r] && x->p2p_peer[r]) (void)hipIpcCloseMemHandle(x->p2p_peer[r]);
   void* ptrs[] = {x->sr, x->si, x->qa, x->qb, x->count, x->tb[0], x->tb[1], x->tbb[0], x->tbb[1], x->qa_base, x->qb_base, x->count_base, x->acc[0], x->acc[1], x->window_own, x->alpha_tab, x->stats, x->d_actions, x->mdpk, x->elog, x->d_mask, x->p2p_buf, x->p2p_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (x->h_actions) (void)hipHostFree(x->h_actions);
+  if (x->h_out) (void)hipHostFree(x->h_out);
+  if (x->ev_actions) (void)hipEventDestroy(x->ev_actions);
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);
   if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -976,16 +1037,55 @@ int dql_reset(dql_ctx* x, const uint8_t* mask) {
 int dql_step(dql_ctx* x, const uint8_t* actions) {
   CHECK_CTX(x);
   if (!actions) return fail(DQL_EINVAL, "actions must not be null (use dql_train_steps / dql_eval_steps for on-device action selection)");
-  for (long long i = 0; i < x->n; ++i) {
-    const int ax = actions[i] & 3, ay = (actions[i] >> 2) & 3;
-    if (ax > 2 || ay > 2 || (actions[i] >> 4) || (!x->cfg.two_axis && ay != 0 && ay != 2))
-      return fail(DQL_EINVAL, "action out of range: ax | ay << 2 with ax, ay in 0..2 (ay only in two_axis configs)");
-  }
   HIP_TRY(hipSetDevice(x->device));
-  HIP_TRY(hipMemcpyAsync(x->d_actions, actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));  // the caller's buffer may be reused right after return
+  // staged through pinned memory: the copy to the device is asynchronous, the caller's buffer is free on return, and nobody waits — except
+  // for the PREVIOUS step's copy out of the same staging buffer, which has long run by the time a caller comes back with new actions
+  if (!x->h_actions) {
+    if (hipHostMalloc((void**)&x->h_actions, (size_t)x->n, hipHostMallocDefault) != hipSuccess) { x->h_actions = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(action staging) failed"); }
+    HIP_TRY(hipEventCreateWithFlags(&x->ev_actions, hipEventDisableTiming));
+  }
+  if (x->actions_in_flight) { HIP_TRY(hipEventSynchronize(x->ev_actions)); x->actions_in_flight = false; }
+  memcpy(x->h_actions, actions, (size_t)x->n);
+  HIP_TRY(hipMemcpyAsync(x->d_actions, x->h_actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipEventRecord(x->ev_actions, x->stream));
+  x->actions_in_flight = true;
   x->ext_actions = nullptr;
-  return launch_period(x, MODE_EXTERNAL, 0.0);
+  return launch_period(x, MODE_EXTERNAL, 0.0);  // the kernel checks the action codes (StatsDev::bad_actions)
+}
+// out-of-range external actions seen by the step kernel since the last report: reported ONCE (the counter is cleared)
+static int report_bad_actions(dql_ctx* x, unsigned long long bad) {
+  if (!bad) return DQL_OK;
+  HIP_TRY(hipMemsetAsync((char*)x->stats + offsetof(StatsDev, bad_actions), 0, sizeof(unsigned long long), x->stream));
+  return fail(DQL_EINVAL, std::to_string(bad) + " action(s) out of range were flown as 'hold': ax | ay << 2 with ax, ay in 0..2 (ay only in two_axis configs)");
+}
+int dql_step_outputs(dql_ctx* x, int32_t* idx_x, int32_t* idx_y, double* reward, uint8_t* done, int8_t* code, int32_t* step_count, double* cum, uint8_t* was_reset) {
+  CHECK_CTX(x);
+  HIP_TRY(hipSetDevice(x->device));
+  const size_t n = (size_t)x->n;
+  if (!x->h_out) {
+    if (hipHostMalloc(&x->h_out, n * sizeof(StepOutRec) + sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { x->h_out = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(step outputs) failed"); }
+    HIP_TRY(hipHostGetDevicePointer(&x->h_out_dev, x->h_out, 0));
+  }
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (x->dtype == DQL_F32) hipLaunchKernelGGL(k_step_outputs<float>, dim3(grid), dim3(256), 0, x->stream, (const Quad<float>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev);
+  else hipLaunchKernelGGL(k_step_outputs<double>, dim3(grid), dim3(256), 0, x->stream, (const Quad<double>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev);
+  HIP_TRY(hipGetLastError());
+  unsigned long long* bad_h = (unsigned long long*)((char*)x->h_out + n * sizeof(StepOutRec));
+  HIP_TRY(hipMemcpyAsync(bad_h, (char*)x->stats + offsetof(StatsDev, bad_actions), sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(wait_stream(x->stream));
+  const StepOutRec* r = (const StepOutRec*)x->h_out;
+  for (size_t i = 0; i < n; ++i) {
+    const int fl = (r[i].code_flags >> 8) & 0xff;
+    if (idx_x) idx_x[i] = r[i].idx_x;
+    if (idx_y) idx_y[i] = r[i].idx_y;
+    if (reward) reward[i] = r[i].reward;
+    if (done) done[i] = (fl & FL_DONE) ? 1 : 0;
+    if (code) code[i] = (int8_t)(r[i].code_flags & 0xff);
+    if (step_count) step_count[i] = r[i].step_count;
+    if (cum) cum[i] = r[i].cum;
+    if (was_reset) was_reset[i] = (fl & FL_WAS_RESET) ? 1 : 0;
+  }
+  return report_bad_actions(x, *bad_h);
 }
 int dql_step_dev(dql_ctx* x, const uint8_t* dev_actions) {
   CHECK_CTX(x);
@@ -1231,7 +1331,8 @@ int dql_set_step_index(dql_ctx* x, int64_t step_index) {
   if (step_index < 0) return fail(DQL_EINVAL, "step_index must be >= 0");
   HIP_TRY(hipSetDevice(x->device));
   { int rc = flush_pending(x); if (rc) return rc; }
-  // the ping-pong buffers are indexed by the parity of step_index: republish so that either parity reads the same tables
+  // the ping-pong buffers follow the parity of launch_index (a launch may cover several periods): republish, so that whichever buffer
+  // the next launch reads holds the same (master) tables
   { int rc = publish_master(x); if (rc) return rc; }
   x->stats_step_base += step_index - x->step_index;  // agent_steps since the last stats reset stays what it was
   x->step_index = step_index;
@@ -1256,6 +1357,12 @@ int dql_stats_get(dql_ctx* x, dql_stats* out) {
   for (int k = 0; k < DQL_N_CHECK_CODES; ++k) out->by_code[k] = (int64_t)s.by_code[k];
   out->reward_sum = (double)s.reward_fx / (double)(1ll << DQL_TARGET_FRAC_BITS);
   out->physics_ticks = ticks_before(x, x->step_index);
+  { int rc = report_bad_actions(x, s.bad_actions); if (rc) return rc; }
+  if (x->p2p_status) {  // the training loop's per-chunk synchronisation point: a table exchange that gave up on a peer ends the run here
+    unsigned long long bad = 0;
+    { int rc = p2p_failed_seq(x, &bad); if (rc) return rc; }
+    if (bad) return fail(DQL_EPEER, "peer-to-peer table exchange " + std::to_string(bad) + " of rank " + std::to_string(x->p2p_rank) + " gave up waiting for a peer (option p2p_spin_limit): its window was not summed, the table replicas differ from here on");
+  }
   return DQL_OK;
 }
 int dql_stats_reset(dql_ctx* x) {
@@ -1487,6 +1594,110 @@ int dql_place(const dql_config* cfg, int device, const double* x0, const double*
   else hipLaunchKernelGGL(k_place<double>, dim3(grid), dim3(256), 0, 0, (int)cfg->init_uniform, (double)cfg->p_max, (const double*)a.p, (const double*)b.p, (long long)n, (double*)o.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, o.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+// ---- resident agent ----
+struct dql_agent {
+  int device = 0;
+  double *qa = nullptr, *qb = nullptr, *count = nullptr;
+  hipStream_t stream = nullptr;
+  void* pin = nullptr; void* pin_dev = nullptr; size_t pin_bytes = 0;  // pinned + device-visible: arguments in, results out
+};
+static int agent_pin(dql_agent* a, size_t bytes) {
+  if (bytes <= a->pin_bytes) return DQL_OK;
+  if (a->pin) { HIP_TRY(hipStreamSynchronize(a->stream)); HIP_TRY(hipHostFree(a->pin)); a->pin = nullptr; a->pin_bytes = 0; }
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  if (hipHostMalloc(&a->pin, bytes, hipHostMallocMapped) != hipSuccess) { a->pin = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(agent staging) failed"); }
+  HIP_TRY(hipHostGetDevicePointer(&a->pin_dev, a->pin, 0));
+  a->pin_bytes = bytes;
+  return DQL_OK;
+}
+#define CHECK_AGENT(a) do { if (!(a)) return fail(DQL_EINVAL, "null agent"); } while (0)
+int dql_agent_create(int device, dql_agent** out) {
+  if (!out) return fail(DQL_EINVAL, "null out pointer");
+  *out = nullptr;
+  OP_PROLOGUE(device)
+  dql_agent* a = new dql_agent();
+  a->device = device;
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  int rc = DQL_OK;
+  do {
+    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(DQL_EHIP, "hipStreamCreate failed"); break; }
+    if (hipMalloc((void**)&a->qa, B) != hipSuccess || hipMalloc((void**)&a->qb, B) != hipSuccess || hipMalloc((void**)&a->count, B) != hipSuccess) { rc = fail(DQL_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMemsetAsync(a->qa, 0, B, a->stream) != hipSuccess || hipMemsetAsync(a->qb, 0, B, a->stream) != hipSuccess || hipMemsetAsync(a->count, 0, B, a->stream) != hipSuccess) { rc = fail(DQL_EHIP, "hipMemset failed"); break; }
+    rc = agent_pin(a, 4096);
+  } while (0);
+  if (rc) { const std::string why = g_err; dql_agent_destroy(a); return fail(rc, why); }
+  *out = a;
+  return DQL_OK;
+}
+int dql_agent_destroy(dql_agent* a) {
+  if (!a) return DQL_OK;
+  (void)hipSetDevice(a->device);
+  if (a->stream) (void)hipStreamSynchronize(a->stream);
+  if (a->qa) (void)hipFree(a->qa);
+  if (a->qb) (void)hipFree(a->qb);
+  if (a->count) (void)hipFree(a->count);
+  if (a->pin) (void)hipHostFree(a->pin);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  delete a;
+  return DQL_OK;
+}
+int dql_agent_set_tables(dql_agent* a, const double* qa, const double* qb, const double* count) {
+  CHECK_AGENT(a);
+  HIP_TRY(hipSetDevice(a->device));
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  if (qa) HIP_TRY(hipMemcpyAsync(a->qa, qa, B, hipMemcpyHostToDevice, a->stream));
+  if (qb) HIP_TRY(hipMemcpyAsync(a->qb, qb, B, hipMemcpyHostToDevice, a->stream));
+  if (count) HIP_TRY(hipMemcpyAsync(a->count, count, B, hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));  // the caller's arrays may change right after return
+  return DQL_OK;
+}
+int dql_agent_get_tables(dql_agent* a, double* qa, double* qb, double* count) {
+  CHECK_AGENT(a);
+  HIP_TRY(hipSetDevice(a->device));
+  const size_t B = DQL_N_CELLS * sizeof(double);
+  if (qa) HIP_TRY(hipMemcpyAsync(qa, a->qa, B, hipMemcpyDeviceToHost, a->stream));
+  if (qb) HIP_TRY(hipMemcpyAsync(qb, a->qb, B, hipMemcpyDeviceToHost, a->stream));
+  if (count) HIP_TRY(hipMemcpyAsync(count, a->count, B, hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return DQL_OK;
+}
+int dql_agent_predict_resident(dql_agent* a, const int32_t* idx, int64_t n, uint8_t* action_out) {
+  CHECK_AGENT(a);
+  if (n < 0 || (n > 0 && (!idx || !action_out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  for (int64_t i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "state index out of range");
+  HIP_TRY(hipSetDevice(a->device));
+  const size_t in_b = ((size_t)n * sizeof(int32_t) + 63) & ~(size_t)63;
+  { int rc = agent_pin(a, in_b + (size_t)n); if (rc) return rc; }
+  memcpy(a->pin, idx, (size_t)n * sizeof(int32_t));
+  hipLaunchKernelGGL(k_predict_resident, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a->stream, (const double*)a->qa, (const double*)a->qb, (const int*)a->pin_dev, (long long)n,
+                     (uint8_t*)a->pin_dev + in_b);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(wait_stream(a->stream));
+  memcpy(action_out, (const char*)a->pin + in_b, (size_t)n);
+  return DQL_OK;
+}
+int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma, const double* reward, int64_t n,
+                              uint32_t quirks, const uint8_t* coin, const uint8_t* done, double* q_new, double* count_new) {
+  CHECK_AGENT(a);
+  if (n < 0 || (n > 0 && (!sa || !ns || !alpha || !reward))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  if (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && !coin) return fail(DQL_EINVAL, "Double Q-learning (DQL_Q_UPDATE_TABLE_A_ONLY cleared) needs the caller's coin per transition");
+  if (!(quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) && !done) return fail(DQL_EINVAL, "bootstrapping on non-terminal transitions (DQL_Q_BOOTSTRAP_ON_POS_CHANGE cleared) needs the done flags");
+  for (int64_t i = 0; i < n; ++i) if (sa[i] < 0 || sa[i] >= DQL_N_CELLS || ns[i] < 0 || ns[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "index out of range");
+  HIP_TRY(hipSetDevice(a->device));
+  const size_t in_b = (size_t)n * sizeof(AgentUpdIn);
+  { int rc = agent_pin(a, in_b + (size_t)n * sizeof(AgentUpdOut)); if (rc) return rc; }
+  AgentUpdIn* in = (AgentUpdIn*)a->pin;
+  for (int64_t i = 0; i < n; ++i) in[i] = AgentUpdIn{sa[i], ns[i], alpha[i], reward[i], coin ? (int)coin[i] : 0, done ? (int)done[i] : 0};
+  hipLaunchKernelGGL(k_update_resident, dim3(1), dim3(64), 0, a->stream, a->qa, a->qb, a->count, (const AgentUpdIn*)a->pin_dev, (AgentUpdOut*)((char*)a->pin_dev + in_b), (long long)n, gamma, quirks);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(wait_stream(a->stream));
+  const AgentUpdOut* o = (const AgentUpdOut*)((const char*)a->pin + in_b);
+  for (int64_t i = 0; i < n; ++i) { if (q_new) q_new[i] = o[i].q_new; if (count_new) count_new[i] = o[i].count_new; }
   return DQL_OK;
 }
 
@@ -1724,12 +1935,15 @@ int dql_p2p_create(dql_ctx* x, int32_t rank, int32_t world, uint8_t* handle_out)
   HIP_TRY(hipSetDevice(x->device));
   const size_t words = (size_t)2 * world * DQL_ACC_LEN + (size_t)2 * DQL_P2P_MAX_RANKS;
   if (hipExtMallocWithFlags((void**)&x->p2p_buf, words * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) { x->p2p_buf = nullptr; return fail(DQL_ENOMEM, "hipExtMallocWithFlags(exchange buffer) failed"); }
-  if (hipMalloc((void**)&x->p2p_status, sizeof(int)) != hipSuccess) { x->p2p_status = nullptr; return fail(DQL_ENOMEM, "hipMalloc failed"); }
+  if (hipMalloc((void**)&x->p2p_status, 2 * sizeof(unsigned long long)) != hipSuccess) { x->p2p_status = nullptr; return fail(DQL_ENOMEM, "hipMalloc failed"); }
   HIP_TRY(hipMemsetAsync(x->p2p_buf, 0, words * sizeof(unsigned long long), x->stream));
-  HIP_TRY(hipMemsetAsync(x->p2p_status, 0, sizeof(int), x->stream));
+  HIP_TRY(hipMemsetAsync(x->p2p_status, 0, 2 * sizeof(unsigned long long), x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   hipIpcMemHandle_t h;
-  HIP_TRY(hipIpcGetMemHandle(&h, x->p2p_buf));
+  {
+    const hipError_t e = hipIpcGetMemHandle(&h, x->p2p_buf);
+    if (e != hipSuccess) return fail(DQL_EHIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) + " (ranks sharing one GPU need HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment before the first HIP call)");
+  }
   memcpy(handle_out, &h, sizeof(h));
   x->p2p_rank = rank; x->p2p_world = world; x->p2p_seq = 0;
   x->p2p_peer[rank] = x->p2p_buf;
@@ -1741,7 +1955,7 @@ int dql_p2p_connect(dql_ctx* x, const uint8_t* all_handles) {
   if (!x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_connect: call dql_p2p_create first");
   HIP_TRY(hipSetDevice(x->device));
   for (int r = 0; r < x->p2p_world; ++r) {
-    if (r == x->p2p_rank || x->p2p_opened[r]) continue;
+    if (r == x->p2p_rank || x->p2p_opened[r] || x->p2p_peer[r]) continue;  // itself, mapped already, or connected by pointer (same process)
     hipIpcMemHandle_t h;
     memcpy(&h, all_handles + (size_t)r * DQL_P2P_HANDLE_BYTES, sizeof(h));
     void* ptr = nullptr;
@@ -1751,11 +1965,40 @@ int dql_p2p_connect(dql_ctx* x, const uint8_t* all_handles) {
   }
   return DQL_OK;
 }
-int dql_p2p_exchange_window(dql_ctx* x) {
+int dql_p2p_connect_local(dql_ctx* x, dql_ctx* const* peers) {
   CHECK_CTX(x);
-  if (!x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_exchange_window: no exchange buffer (dql_p2p_create / dql_p2p_connect)");
-  if (!x->windowed) return fail(DQL_ESTATE, "dql_p2p_exchange_window needs windowed accumulation (dql_set_windowed)");
-  for (int r = 0; r < x->p2p_world; ++r) if (!x->p2p_peer[r]) return fail(DQL_ESTATE, "dql_p2p_exchange_window: not connected to every peer (dql_p2p_connect)");
+  if (!peers) return fail(DQL_EINVAL, "null pointer");
+  if (!x->p2p_buf) return fail(DQL_ESTATE, "dql_p2p_connect_local: call dql_p2p_create first");
+  HIP_TRY(hipSetDevice(x->device));
+  for (int r = 0; r < x->p2p_world; ++r) {
+    dql_ctx* pr = peers[r];
+    if (!pr || r == x->p2p_rank) continue;
+    if (!pr->p2p_buf || pr->p2p_rank != r || pr->p2p_world != x->p2p_world) return fail(DQL_EINVAL, "dql_p2p_connect_local: peers[r] must be the context that called dql_p2p_create(rank r, same world)");
+    if (pr->device != x->device) {
+      const hipError_t e = hipDeviceEnablePeerAccess(pr->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(DQL_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    x->p2p_peer[r] = pr->p2p_buf;
+  }
+  return DQL_OK;
+}
+static int p2p_ready(dql_ctx* x, const char* who) {
+  if (!x->p2p_buf) return fail(DQL_ESTATE, std::string(who) + ": no exchange buffer (dql_p2p_create / dql_p2p_connect)");
+  if (!x->windowed) return fail(DQL_ESTATE, std::string(who) + " needs windowed accumulation (dql_set_windowed)");
+  for (int r = 0; r < x->p2p_world; ++r) if (!x->p2p_peer[r]) return fail(DQL_ESTATE, std::string(who) + ": not connected to every peer (dql_p2p_connect / dql_p2p_connect_local)");
+  return DQL_OK;
+}
+static P2PPushArgs p2p_args(dql_ctx* x, unsigned long long seq) {
+  P2PPushArgs a;
+  a.window = x->window; a.rank = x->p2p_rank; a.world = x->p2p_world; a.parity = (int)(seq & 1);
+  for (int r = 0; r < DQL_P2P_MAX_RANKS; ++r) a.peer[r] = r < x->p2p_world ? x->p2p_peer[r] : nullptr;
+  return a;
+}
+int dql_p2p_push_window(dql_ctx* x) {
+  CHECK_CTX(x);
+  { int rc = p2p_ready(x, "dql_p2p_push_window"); if (rc) return rc; }
+  if (x->p2p_pushed) return fail(DQL_ESTATE, "dql_p2p_push_window: the previous push has not been waited for (dql_p2p_wait_window)");
   HIP_TRY(hipSetDevice(x->device));
   { int rc = flush_pending(x); if (rc) return rc; }  // the last launch's accumulators enter the window here
   if (x->kernel_timer) {
@@ -1764,25 +2007,39 @@ int dql_p2p_exchange_window(dql_ctx* x) {
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, x->stream)); x->sev.push_back(e0);
   }
   const unsigned long long seq = ++x->p2p_seq;
-  P2PPushArgs a;
-  a.window = x->window; a.rank = x->p2p_rank; a.world = x->p2p_world; a.parity = (int)(seq & 1);
-  for (int r = 0; r < DQL_P2P_MAX_RANKS; ++r) a.peer[r] = r < x->p2p_world ? x->p2p_peer[r] : nullptr;
+  const P2PPushArgs a = p2p_args(x, seq);
   const int B = 256, G = (DQL_ACC_LEN + B - 1) / B;
   hipLaunchKernelGGL(k_p2p_push, dim3(G), dim3(B), 0, x->stream, a);
   hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, x->stream, a, seq);
-  hipLaunchKernelGGL(k_p2p_wait_sum, dim3(G), dim3(B), 0, x->stream, x->p2p_buf, x->window, x->p2p_world, a.parity, seq, x->p2p_status, x->p2p_spin_limit);
   HIP_TRY(hipGetLastError());
+  x->p2p_pushed = true;
   return DQL_OK;
 }
-int dql_p2p_status(dql_ctx* x, int32_t* failed) {
+int dql_p2p_wait_window(dql_ctx* x) {
   CHECK_CTX(x);
-  if (!failed) return fail(DQL_EINVAL, "null pointer");
-  if (!x->p2p_status) { *failed = 0; return DQL_OK; }
+  { int rc = p2p_ready(x, "dql_p2p_wait_window"); if (rc) return rc; }
+  if (!x->p2p_pushed) return fail(DQL_ESTATE, "dql_p2p_wait_window: nothing pushed (dql_p2p_push_window)");
   HIP_TRY(hipSetDevice(x->device));
-  int v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, x->p2p_status, sizeof(int), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
-  *failed = v;
+  const unsigned long long seq = x->p2p_seq;
+  const int parity = (int)(seq & 1);
+  const int B = 256, G = (DQL_ACC_LEN + B - 1) / B;
+  hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, x->stream, (const unsigned long long*)x->p2p_buf, x->p2p_world, parity, seq, x->p2p_status, x->p2p_spin_limit);
+  hipLaunchKernelGGL(k_p2p_sum, dim3(G), dim3(B), 0, x->stream, x->p2p_buf, x->window, x->p2p_world, parity, seq, (const unsigned long long*)x->p2p_status);
+  HIP_TRY(hipGetLastError());
+  x->p2p_pushed = false;
+  return DQL_OK;
+}
+int dql_p2p_exchange_window(dql_ctx* x) {
+  const int rc = dql_p2p_push_window(x);
+  return rc ? rc : dql_p2p_wait_window(x);
+}
+int dql_p2p_status(dql_ctx* x, int32_t* failed_seq) {
+  CHECK_CTX(x);
+  if (!failed_seq) return fail(DQL_EINVAL, "null pointer");
+  HIP_TRY(hipSetDevice(x->device));
+  unsigned long long v = 0;
+  { int rc = p2p_failed_seq(x, &v); if (rc) return rc; }
+  *failed_seq = (int32_t)(v > 0x7fffffffull ? 0x7fffffffull : v);
   return DQL_OK;
 }
 

@@ -49,6 +49,22 @@ class P2PWindowReducer:
         handles = (gather or gather_via_files)(tag, self.rank, self.world, handle)
         engine.p2p_connect(handles)
 
+    @classmethod
+    def local_group(cls, engines):
+        """Reducers for ranks that all live in THIS process (one host thread driving several contexts / GPUs): buffers connected by
+        pointer, no IPC, nothing to gather.  Drive them with `ShardedGroup`, which enqueues every rank's push before any rank's wait
+        (streams of one process may share a hardware queue: a wait kernel queued ahead of the push it waits for would sit there until
+        its poll bound)."""
+        reds = []
+        for r, e in enumerate(engines):
+            red = cls.__new__(cls)
+            red.engine, red.rank, red.world = e, r, len(engines)
+            e.p2p_create(r, len(engines))
+            reds.append(red)
+        for e in engines:
+            e.p2p_connect_local(engines)
+        return reds
+
     def all_reduce(self):
         self.engine.p2p_exchange_window()  # flush + push + signal + wait + sum, asynchronous on the engine's stream
 
@@ -92,4 +108,39 @@ class ShardedRunner:
         if self.reducer is not None and self._since > 0:
             self.reducer.all_reduce()
             self.engine.apply_accum()
+        self._since = 0
+
+
+
+class ShardedGroup:
+    """Several ranks driven by ONE host thread ("one host thread drives all contexts, or one per GPU"): the same
+    schedule as one `ShardedRunner` per rank, with the peer-to-peer exchange issued in two sweeps — all pushes, then all waits + folds."""
+
+    def __init__(self, engines, sync_period: int = 1):
+        if sync_period < 1:
+            raise ValueError("sync_period must be >= 1")
+        self.engines, self.sync_period = list(engines), int(sync_period)
+        self.reducers = P2PWindowReducer.local_group(self.engines)
+        self._since = 0
+        for e in self.engines:
+            e.set_windowed(True)
+
+    def train_steps(self, n_steps: int, eps: float):
+        left = int(n_steps)
+        while left > 0:
+            k = min(left, self.sync_period - self._since)
+            for e in self.engines:
+                e.train_steps(k, eps)
+            self._since += k
+            left -= k
+            if self._since == self.sync_period:
+                self.sync()
+
+    def sync(self):
+        if self._since > 0:
+            for e in self.engines:
+                e.p2p_push_window()
+            for e in self.engines:
+                e.p2p_wait_window()
+                e.apply_accum()
         self._since = 0

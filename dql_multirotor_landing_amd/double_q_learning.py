@@ -5,13 +5,16 @@ reference's `np.random` numbers so that a seeded run consumes the global MT19937
 does (B1, B4)."""
 from __future__ import annotations
 
+import os
 from pathlib import Path
 from typing import Tuple, Union
 
 import numpy as np
 
-from . import ops
-from .config import MAX_LEVELS, Q_PAPER, Q_REFERENCE, TABLE_SHAPE
+import ctypes as C
+
+from . import _lib, ops
+from .config import MAX_LEVELS, N_CELLS, Q_PAPER, Q_REFERENCE, TABLE_SHAPE
 from .mdp import pack_state
 
 State = Tuple[int, int, int, int, int]
@@ -39,13 +42,43 @@ class DoubleQLearningAgent:
         self.Q_table_b = np.zeros(shape)
         self.state_action_counter = np.zeros(shape)
         self._device = device
+        self._res = None      # dql_agent*: the tables resident on the device between calls (created on first use)
+        self._shadow = None   # what the device holds, padded to 5 levels: (qa, qb, count)
+
+    # ---- resident device tables (include/dql.h dql_agent_*) ----
+    def _resident(self):
+        """The device copy of the tables, brought up to date if the host arrays were written since (they are public attributes: the
+        comparison against the shadow of what was last uploaded IS the dirty flag — 3 x 22 KB of memcmp instead of 3 x 22 KB over PCIe)."""
+        lib = _lib.load()
+        if self._res is None:
+            h = C.c_void_p()
+            _lib.check(lib.dql_agent_create(self._device, C.byref(h)))
+            self._res = h
+        host = self._padded()
+        if self._shadow is None or not all(np.array_equal(a, b) for a, b in zip(host, self._shadow)):
+            _lib.check(lib.dql_agent_set_tables(self._res, *[a.ctypes.data_as(C.c_void_p) for a in host]))
+            self._shadow = host
+        return lib, self._res
+
+    def close(self):
+        if getattr(self, "_res", None):
+            _lib.load().dql_agent_destroy(self._res)
+            self._res = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- persistence: pkg/double_q_learning.py:42-75 ----
     def save(self, save_path: Path):
         save_path = Path(save_path)
         for name, arr in (("Q_table_a.npy", self.Q_table_a), ("Q_table_b.npy", self.Q_table_b), ("state_action_count.npy", self.state_action_counter)):
-            with open(save_path / name, "wb") as f:
+            tmp = save_path / f".{name}.{os.getpid()}.tmp"  # same bytes as the reference's np.save; a reader never sees half a table
+            with open(tmp, "wb") as f:
                 np.save(f, np.ascontiguousarray(arr, dtype=np.float64))
+            os.replace(tmp, save_path / name)
 
     @staticmethod
     def load(save_path: Path = ASSETS_PATH):
@@ -68,6 +101,8 @@ class DoubleQLearningAgent:
             out = np.zeros(TABLE_SHAPE, dtype=np.float64)
             out[: self.curriculum_steps] = t
             return out.reshape(-1)
+        if self.curriculum_steps == MAX_LEVELS:
+            return tuple(np.array(t, dtype=np.float64, order="C").reshape(-1) for t in (self.Q_table_a, self.Q_table_b, self.state_action_counter))
         return pad(self.Q_table_a), pad(self.Q_table_b), pad(self.state_action_counter)
 
     def _unpad(self, qa, qb, cnt):
@@ -106,14 +141,24 @@ class DoubleQLearningAgent:
         sa = self._check_state(current_state_action, 6)
         ns = self._check_state(next_state, 5)
         u = np.random.uniform(0, 1)  # reference: drawn and ignored, both arms select Q_table_a (B1); paper mode: the coin
-        qa, qb, cnt = self._padded()
+        lib, res = self._resident()
+        cell = pack_state(sa[:5]) * 3 + sa[5]
+        i32 = lambda v: np.array([v], dtype=np.int32); f64 = lambda v: np.array([float(v)], dtype=np.float64)
+        a_sa, a_ns, a_al, a_rw = i32(cell), i32(pack_state(ns)), f64(alpha), f64(reward)
+        q_new, c_new = np.zeros(1), np.zeros(1)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        sel_b = False
         if self.mode == "reference":
-            ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
-                             quirks=Q_REFERENCE, device=self._device)
+            _lib.check(lib.dql_agent_update_resident(res, p(a_sa), p(a_ns), p(a_al), float(gamma), p(a_rw), 1, Q_REFERENCE, None, None, p(q_new), p(c_new)))
         else:
-            ops.agent_update(qa, qb, cnt, [pack_state(sa[:5]) * 3 + sa[5]], [pack_state(ns)], [float(alpha)], float(gamma), [float(reward)],
-                             quirks=Q_PAPER, device=self._device, coin=[0 if u < 0.5 else 1], done=[1 if done else 0])
-        self._unpad(qa, qb, cnt)
+            sel_b = not u < 0.5
+            coin, dn = np.array([1 if sel_b else 0], dtype=np.uint8), np.array([1 if done else 0], dtype=np.uint8)
+            _lib.check(lib.dql_agent_update_resident(res, p(a_sa), p(a_ns), p(a_al), float(gamma), p(a_rw), 1, Q_PAPER, p(coin), p(dn), p(q_new), p(c_new)))
+        # the kernel reports the one cell it changed and its visit counter: patch the host arrays and the shadow of the device copy
+        (self.Q_table_b if sel_b else self.Q_table_a)[sa] = q_new[0]
+        self.state_action_counter[sa] = c_new[0]
+        self._shadow[1 if sel_b else 0][cell] = q_new[0]
+        self._shadow[2][cell] = c_new[0]
 
     # ---- pkg/double_q_learning.py:110-124 ----
     def guess(self, state: State, exploration_rate: float):
@@ -122,7 +167,9 @@ class DoubleQLearningAgent:
 
     def predict(self, state: State):
         s = self._check_state(state, 5)
-        qa, qb, _ = self._padded()
-        return int(ops.agent_predict(qa, qb, [pack_state(s)], device=self._device)[0])
+        lib, res = self._resident()
+        idx = np.array([pack_state(s)], dtype=np.int32); out = np.zeros(1, dtype=np.uint8)
+        _lib.check(lib.dql_agent_predict_resident(res, idx.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+        return int(out[0])
 
     get_action = guess  # name used by BASELINE.json's north_star

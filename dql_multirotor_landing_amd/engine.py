@@ -103,8 +103,20 @@ class Engine:
         return a.value, b.value
 
     def field_names(self, is_int=False):
-        n = self.n_fields()[1 if is_int else 0]
-        return [self.lib.dql_field_name(i, int(is_int)).decode() for i in range(n)]
+        cache = self.__dict__.setdefault("_names", {})
+        if is_int not in cache:  # 64 + 7 ctypes calls: made once (the single-env drop-ins ask every step)
+            n = self.n_fields()[1 if is_int else 0]
+            cache[is_int] = [self.lib.dql_field_name(i, int(is_int)).decode() for i in range(n)]
+        return list(cache[is_int])
+
+    def step_outputs(self):
+        """what `TrainingLandingEnv.step` returns, for every env, in one device round trip (include/dql.h dql_step_outputs):
+        dict of arrays idx_x, idx_y, reward, done, code, step_count, cumulative_reward, was_reset"""
+        n = self.n
+        o = {"idx_x": np.zeros(n, np.int32), "idx_y": np.zeros(n, np.int32), "reward": np.zeros(n, np.float64), "done": np.zeros(n, np.uint8),
+             "code": np.zeros(n, np.int8), "step_count": np.zeros(n, np.int32), "cumulative_reward": np.zeros(n, np.float64), "was_reset": np.zeros(n, np.uint8)}
+        _lib.check(self.lib.dql_step_outputs(self._h, *[_p(o[k]) for k in ("idx_x", "idx_y", "reward", "done", "code", "step_count", "cumulative_reward", "was_reset")]))
+        return o
 
     def get_fields(self):
         nr, ni = self.n_fields()
@@ -187,13 +199,29 @@ class Engine:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         _lib.check(self.lib.dql_p2p_connect(self._h, buf))
 
+    def p2p_connect_local(self, peers):
+        """peers: the Engines of ALL ranks in rank order, None where a rank lives in another process (those: p2p_connect)"""
+        arr = (C.c_void_p * len(peers))(*[None if e is None else e._h for e in peers])
+        _lib.check(self.lib.dql_p2p_connect_local(self._h, arr))
+
     def p2p_exchange_window(self):
         _lib.check(self.lib.dql_p2p_exchange_window(self._h))
 
-    def p2p_failed(self) -> bool:
+    def p2p_push_window(self):
+        _lib.check(self.lib.dql_p2p_push_window(self._h))
+
+    def p2p_wait_window(self):
+        _lib.check(self.lib.dql_p2p_wait_window(self._h))
+
+    def p2p_failed_seq(self) -> int:
+        """sequence number (1-based) of the first exchange that gave up on a missing peer, 0 = none.  `stats()` raises RuntimeError once
+        this is non-zero: the training loop's per-chunk synchronisation point ends a run whose replicas have diverged."""
         v = C.c_int32(0)
         _lib.check(self.lib.dql_p2p_status(self._h, C.byref(v)))
-        return bool(v.value)
+        return int(v.value)
+
+    def p2p_failed(self) -> bool:
+        return self.p2p_failed_seq() != 0
 
     def sync_time_ms(self):
         ms = C.c_double(); n = C.c_int64()

@@ -46,13 +46,9 @@ class VecLandingEnv:
 
     def step(self, actions):
         self.engine.step(actions)
-        reals, ints = self.engine.get_fields()
-        names = self.engine.field_names(); inames = self.engine.field_names(True)
-        idx = ints[inames.index("idx_x")]
-        flags = ints[inames.index("flags")]
-        info = {"check_code": ints[inames.index("code")].copy(), "step_count": ints[inames.index("step_count")].copy(),
-                "cumulative_reward": reals[names.index("cum_x")].copy(), "was_reset": (flags & 8) != 0}
-        return self._tuples(idx), reals[names.index("reward")].copy(), (flags & 1) != 0, info
+        o = self.engine.step_outputs()  # one device round trip (no full state download)
+        info = {"check_code": o["code"].astype(np.int32), "step_count": o["step_count"], "cumulative_reward": o["cumulative_reward"], "was_reset": o["was_reset"] != 0}
+        return self._tuples(o["idx_x"]), o["reward"], o["done"] != 0, info
 
     def close(self):
         self.engine.close()

@@ -60,7 +60,9 @@ from __future__ import annotations
 import csv
 import json
 import math
+import os
 import time
+import warnings
 from collections import deque
 from datetime import datetime
 from pathlib import Path
@@ -93,7 +95,7 @@ class Trainer:
                  initial_curriculum_step: int = 0, seed: int = 42, save_path=None, *, alpha_min: float = 0.02949, omega: float = 0.51,
                  gamma: float = 0.99, scale_modification_value=(0.8172650252856599, 0.8211253690681617, 0.8257273369742982, 0.8311571820651724),
                  t_max: int = 20, z_init: float = 4.0, f_ag: float = 22.92, p_max: float = 4.5,
-                 n_envs: int = 4096, device: int = 0, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
+                 n_envs: int = 4096, device: Optional[int] = None, dtype: int = F32, mode: str = "reference", chunk_steps: int = 64,
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
@@ -121,7 +123,7 @@ class Trainer:
         self._curriculum_episode_count = 0
         self._successes = deque([], maxlen=successive_successful_episodes)
         # build-specific
-        self._n_envs, self._device, self._dtype, self._mode = int(n_envs), device, dtype, mode
+        self._n_envs, self._dtype, self._mode = int(n_envs), dtype, mode
         # the reference's 50 000 episodes per level are sized for ONE env; with N envs the level has to last until the judged env(s)
         # have flown a few hundred episodes (the deque wants 100 of them), i.e. a few hundred episodes PER env
         self._max_num_episodes = max(50000, 384 * self._n_envs) if max_num_episodes is None else int(max_num_episodes)
@@ -140,7 +142,11 @@ class Trainer:
         self._eps_tail_after = float(eps_tail_after)
         if not 1 <= self._periods_per_launch <= 8 or self._chunk_steps % self._periods_per_launch:
             raise ValueError("periods_per_launch must be in 1..8 and divide chunk_steps")
+        # device None: GPU LOCAL_RANK of a multi-rank launch (one process per GPU), GPU 0 of a single process; an explicit device wins
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
+        self._device_arg = device
+        self._device = int(device) if device is not None else (getattr(self._comm, "device", 0) if self._comm else 0)
+        self._save_generation = 0  # checkpoints written by this Trainer (every rank counts the same ones)
         self._reducer_factory = reducer_factory
         self._rank = self._comm.rank if self._comm else 0
         self._world = self._comm.world if self._comm else 1
@@ -179,8 +185,9 @@ class Trainer:
 
     # ---- checkpoints: pkg/trainer.py:140-167 (same .npy names, run dir + copy one level up) ----
     def _state_dict(self):
-        build = {k: getattr(self, "_" + k) for k in _BUILD_KEYS if k != "judge_envs"}
+        build = {k: getattr(self, "_" + k) for k in _BUILD_KEYS if k not in ("judge_envs", "device")}
         build["judge_envs"] = self._judge_envs_arg
+        build["device"] = self._device_arg  # None stays None: a resumed multi-rank job again takes LOCAL_RANK
         return {"curriculum_steps": self._curriculum_steps, "working_curriculum_step": self._working_curriculum_step,
                 "current_episode": self._current_episode, "curriculum_episode_count": self._curriculum_episode_count,
                 "seed": self._seed, "alpha_min": self._alpha_min, "omega": self._omega, "gamma": self._gamma,
@@ -192,24 +199,46 @@ class Trainer:
     def _env_state_file(self, rank: int) -> Path:
         return self._save_path / f"env_state_rank{rank}.npz"
 
+    def _checkpoint_tag(self):
+        """What ties the files of ONE checkpoint together: every rank is at the same (level, agent periods, chunk) when it saves, and
+        counts the same checkpoints.  Stored in every env_state_rank*.npz and in trainer.json's progress."""
+        pr = self._progress or {}
+        return {"level": int(pr.get("level", -1)), "steps": int(pr.get("steps", -1)), "chunk_i": int(pr.get("chunk_i", -1)),
+                "world": int(self._world), "generation": int(self._save_generation)}
+
     def save(self) -> None:
+        """One checkpoint = env_state_rank<r>.npz of every rank + the three .npy tables + trainer.json, every file written as temp +
+        os.replace, trainer.json LAST (and, with several ranks, after a barrier): a run killed anywhere in between leaves the previous
+        trainer.json, whose tag the newer env-state files do not match — `load()` then resumes the level from its tables without them."""
         eng = self._engine
         if eng is not None and hasattr(eng, "publish_tables"):
             eng.publish_tables()  # checkpoint = table barrier: pending updates folded, acting tables = master tables (a resumed run starts so)
         self._pull_tables()
+        self._save_generation += 1
+        tag = self._checkpoint_tag()
         if eng is not None and self._checkpoint_env_state and self._progress is not None and hasattr(eng, "get_fields"):
             # every rank writes its own shard: simulator state of every env + the period index the RNG and tick schedule hang on
             self._save_path.mkdir(parents=True, exist_ok=True)
             reals, ints = eng.get_fields()
-            np.savez(self._env_state_file(self._rank), reals=reals.astype(np.float32 if self._dtype == F32 else np.float64), ints=ints,
-                     step_index=np.int64(eng.step_index()))
+            f = self._env_state_file(self._rank)
+            tmp = f.with_name(f".{f.name}.{os.getpid()}.tmp.npz")
+            np.savez(tmp, reals=reals.astype(np.float32 if self._dtype == F32 else np.float64), ints=ints, step_index=np.int64(eng.step_index()),
+                     **{f"tag_{k}": np.int64(v) for k, v in tag.items()})
+            os.replace(tmp, f)
+        if self._comm is not None and self._world > 1:
+            self._comm.barrier()  # every rank's shard of this checkpoint is on disk before rank 0 publishes it
         if self._rank != 0:  # table replicas are identical after a sync: rank 0 writes
             return
         self._save_path.mkdir(parents=True, exist_ok=True)
-        with open(self._save_path / "trainer.json", "w") as f:
-            json.dump(self._state_dict(), f, indent=1)
         self._double_q_learning_agent.save(self._save_path)
         self._double_q_learning_agent.save(self._save_path / "..")
+        st = self._state_dict()
+        if st["progress"] is not None:
+            st["progress"] = dict(st["progress"], tag=tag)
+        tmp = self._save_path / f".trainer.json.{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
+            json.dump(st, fh, indent=1)
+        os.replace(tmp, self._save_path / "trainer.json")
 
     @staticmethod
     def load(assets_path: Path = ASSETS_PATH, **kw) -> "Trainer":
@@ -260,7 +289,7 @@ class Trainer:
 
     # ---- pkg/trainer.py:169-245 ----
     def _make_engine(self, cfg):
-        sync = self._sync_period if self._sync_period is not None else (2 if self._world > 1 else None)
+        sync = self._sync_period if self._sync_period is not None else (2 if (self._world > 1 or self._reducer_factory is not None) else None)
         if self._world > 1 or self._reducer_factory is not None or sync is not None:
             if self._chunk_steps % sync or sync % self._periods_per_launch:
                 raise ValueError("chunk_steps must be a multiple of sync_period (checkpoints and promotions happen on synchronised tables) and sync_period of periods_per_launch")
@@ -324,18 +353,39 @@ class Trainer:
             return self._alpha
         return float((np.sum(total(cnt_after)) - np.sum(total(cnt_before))) / visits)
 
-    def _restore_env_state(self, eng):
+    def _load_env_state(self, eng, progress):
+        """This rank's env-state file if it is of the checkpoint `progress` belongs to, else None: there is no file, a rank was killed
+        between its shard and rank 0's trainer.json, the file is a leftover of an earlier level, the world size changed."""
         f = self._env_state_file(self._rank)
         if not (self._checkpoint_env_state and f.exists() and hasattr(eng, "set_fields")):
-            return False
+            return None
         z = np.load(f, allow_pickle=False)
+        want = progress.get("tag")
+        have = {k[4:]: int(z[k]) for k in z.files if k.startswith("tag_")}
+        if want is None or have != {k: int(v) for k, v in want.items()}:
+            warnings.warn(f"{f.name} belongs to checkpoint {have or 'without a tag'}, trainer.json to {want}: resuming level {progress.get('level')} "
+                          "from its tables without the saved simulator state", RuntimeWarning)
+            return None
         if z["ints"].shape[1] != eng.n:
             raise ValueError(f"{f} holds {z['ints'].shape[1]} envs, this rank's shard has {eng.n}")
+        return z
+
+    def _restore_env_state(self, eng, progress):
+        """Simulator state of the envs from the checkpoint `progress` belongs to — on every rank, or on none (then the level's envs
+        start over, its bookkeeping does not)."""
+        z = self._load_env_state(eng, progress)
+        ok = z is not None
+        if self._comm is not None and self._world > 1:
+            ok = bool(self._comm.all_reduce_sum([0.0 if ok else 1.0])[0] == 0.0)
+        if not ok:
+            return False
         eng.set_fields(z["reals"].astype(np.float64), z["ints"])
         eng.set_step_index(int(z["step_index"]))
         return True
 
     def curriculum_training(self):
+        if self._working_curriculum_step >= self._curriculum_steps:  # Trainer.load() of a finished run: nothing left to train
+            return self.history
         t_start = time.perf_counter()
         resume, self._resume = self._resume, None
         cfg = self._config(self._working_curriculum_step)
@@ -354,7 +404,7 @@ class Trainer:
             resumed = resume is not None and k == first_level and resume.get("level") == k
             if resumed:
                 # continue the interrupted level: no transfer (it was applied when the level started), tables as checkpointed
-                have_envs = self._restore_env_state(eng)
+                have_envs = self._restore_env_state(eng, resume)
                 if not have_envs:
                     eng.set_curriculum(k)  # no simulator state saved: the level's envs start over, its bookkeeping does not
                 pr = resume
@@ -432,6 +482,10 @@ class Trainer:
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))
             self._progress = None  # between levels: a resumed run starts the next level from its beginning
+            try:  # this level's simulator state is of no use to the next one
+                self._env_state_file(self._rank).unlink()
+            except OSError:
+                pass
             if promoted or exhausted:
                 self._working_curriculum_step = min(k + 1, self._curriculum_steps)  # what a checkpoint taken now resumes at
                 self.save()

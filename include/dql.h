@@ -30,7 +30,8 @@ typedef enum dql_status {
   DQL_EHIP = -2,   /* HIP runtime error (Python: RuntimeError) */
   DQL_ESTATE = -3, /* call order violation, e.g. step before reset (Python: ValueError) */
   DQL_ENOMEM = -4,
-  DQL_ERCCL = -5   /* RCCL error, or librccl could not be loaded (Python: RuntimeError) */
+  DQL_ERCCL = -5,  /* RCCL error, or librccl could not be loaded (Python: RuntimeError) */
+  DQL_EPEER = -6   /* a peer-to-peer table exchange gave up on a missing peer: the replicas may differ from here on (Python: RuntimeError) */
 } dql_status;
 
 /* CheckResult codes, declaration order of pkg/mdp.py:68-77 */
@@ -163,8 +164,16 @@ int dql_set_curriculum(dql_ctx* ctx, int32_t working_curriculum_step);
 /* mark envs for reset (mask NULL = all); the reset (placement + one agent period + first discrete state)
  * is executed by the next step/train call, as the reference's reset() runs one agent period of simulation */
 int dql_reset(dql_ctx* ctx, const uint8_t* mask_or_null);
-/* one agent step with caller-supplied actions (uint8 per env, 0/1/2; two_axis: 2 per env); no table update */
+/* one agent step with caller-supplied actions (uint8 per env: ax | ay << 2, ax, ay in 0 / 1 / 2, ay only in two_axis configs); no table
+ * update.  The actions are staged through pinned host memory and checked BY THE KERNEL (no host loop over n_envs, no wait): an
+ * out-of-range action is flown as "hold" and makes the next dql_step_outputs / dql_stats_get return DQL_EINVAL once. */
 int dql_step(dql_ctx* ctx, const uint8_t* actions);
+/* what `TrainingLandingEnv.step` returns (pkg/landing_simulation_env.py:245-282), for every env, in ONE device round trip: packed
+ * states, reward, done ("Termination condition" in info), CheckResult code, "Number of steps", cumulative reward (after this step's
+ * reward), and whether the env spent the period in reset().  Any output may be NULL.  The step kernel's results are gathered into
+ * pinned host memory by a small kernel on the context's stream; the call returns when it has run. */
+int dql_step_outputs(dql_ctx* ctx, int32_t* idx_x, int32_t* idx_y, double* reward, uint8_t* done, int8_t* code, int32_t* step_count,
+                     double* cumulative_reward, uint8_t* was_reset);
 /* same with the actions already in device memory (n_envs bytes, readable on the context's device): no copy, no host-side
  * validation, fully asynchronous (the buffer must stay valid until the step has run); values other than 0 / 1 act as "hold" */
 int dql_step_dev(dql_ctx* ctx, const uint8_t* dev_actions);
@@ -251,14 +260,28 @@ int dql_allreduce_window(dql_ctx* ctx);
  *   dql_p2p_create(ctx, rank, world, handle)  -> 64-byte IPC handle of this rank's buffer; gather all ranks' handles (any way:
  *   dql_comm_allgather_u64, files, ...), dql_p2p_connect(ctx, handles in rank order), then per exchange
  *   dql_p2p_exchange_window(ctx) (asynchronous, on the context's stream; includes the flush) followed by dql_apply_accum(ctx) —
- *   the drop-in for dql_allreduce_window.  A peer that never shows up makes the wait give up after a few seconds of polling instead
- *   of hanging the GPU: dql_p2p_status reports it (failed = 1) and the window is then NOT the sum.  world <= DQL_P2P_MAX_RANKS. */
+ *   the drop-in for dql_allreduce_window.  A peer that never shows up makes the wait give up after option "p2p_spin_limit" polls
+ *   (default 60 M, a minute or two) instead of hanging the GPU.  ONE waiter decides per exchange: the window is then either the full
+ *   sum or untouched (this rank's own accumulators), never half-summed; the sequence number of the first failed exchange is kept
+ *   (dql_p2p_status: failed_seq, 0 = none) and from then on dql_stats_get — the per-chunk synchronisation point of the training
+ *   loop — returns DQL_EPEER, so a training run cannot carry on with diverging replicas.  world <= DQL_P2P_MAX_RANKS.
+ *   Ranks that share ONE GPU (tests, rehearsals) need HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment before the first HIP call:
+ *   the host driver only supports dmabuf IPC, and hipIpcGetMemHandle fails with "invalid argument" without it. */
 #define DQL_P2P_HANDLE_BYTES 64
 #define DQL_P2P_MAX_RANKS 8
 int dql_p2p_create(dql_ctx* ctx, int32_t rank, int32_t world, uint8_t* handle_out);
 int dql_p2p_connect(dql_ctx* ctx, const uint8_t* all_handles);
+/* peers that live in THIS process (one host thread driving several contexts, SURVEY.md section 8b "threading"): their exchange buffers
+ * are connected by pointer instead of through an IPC handle (which cannot be opened by the process that exported it).  peers[world] in
+ * rank order, NULL for ranks of other processes (those come through dql_p2p_connect).  Peer access between devices is enabled here. */
+int dql_p2p_connect_local(dql_ctx* ctx, dql_ctx* const* peers);
 int dql_p2p_exchange_window(dql_ctx* ctx);
-int dql_p2p_status(dql_ctx* ctx, int32_t* failed);
+/* the two halves of dql_p2p_exchange_window, for a host thread that drives several ranks: enqueue EVERY local rank's push (flush +
+ * push + signal) before any local rank's wait (wait + sum) — streams of one process may share a hardware queue, and a wait kernel
+ * queued ahead of the push it waits for would only end at its poll bound */
+int dql_p2p_push_window(dql_ctx* ctx);
+int dql_p2p_wait_window(dql_ctx* ctx);
+int dql_p2p_status(dql_ctx* ctx, int32_t* failed_seq);
 /* average device time of the exchanges (all-reduce + fold) made while the kernel timer was armed (dql_kernel_timer) */
 int dql_sync_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* syncs);
 
@@ -330,6 +353,21 @@ int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n
 /* start coordinate of the drone along one axis for n (random offset x0, platform coordinate) pairs: the placement arithmetic of
  * TrainingLandingEnv.reset / SimulationLandingEnv.reset selected by cfg->init_uniform (see dql_config) */
 int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out);
+/* ---- a DoubleQLearningAgent's tables RESIDENT on the device (pkg/double_q_learning.py:32-146) ----
+ * The stateless dql_agent_predict / dql_agent_update below ship all three tables (3 x 22 680 B) both ways per call — fine for a batch,
+ * 6x slower than the reference's own Python for a caller that steps ONE env (BASELINE configs[0]).  A dql_agent keeps them in device
+ * memory between calls; arguments and results travel through pinned host memory the kernels read and write directly (one launch
+ * and one wait per call, no allocation, no copy engine).  dql_agent_update_resident returns, per transition, the new value of the
+ * updated cell and of its visit counter, so the caller can patch its host copy of the tables instead of fetching them. */
+typedef struct dql_agent dql_agent;
+int dql_agent_create(int device, dql_agent** out);
+int dql_agent_destroy(dql_agent* agent);
+int dql_agent_set_tables(dql_agent* agent, const double* qa_or_null, const double* qb_or_null, const double* count_or_null);
+int dql_agent_get_tables(dql_agent* agent, double* qa_or_null, double* qb_or_null, double* count_or_null);
+int dql_agent_predict_resident(dql_agent* agent, const int32_t* idx, int64_t n, uint8_t* action_out);
+int dql_agent_update_resident(dql_agent* agent, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma, const double* reward,
+                              int64_t n, uint32_t quirks, const uint8_t* coin_or_null, const uint8_t* done_or_null, double* q_new_out,
+                              double* count_new_out);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:

@@ -87,3 +87,43 @@ def test_gather_via_files_two_ranks(tmp_path, monkeypatch):
         t.join(60)
     assert res[0] == res[1] == [bytes([0]) * 64, bytes([1]) * 64]
     assert not list(tmp_path.glob("*.bin"))
+
+
+def test_bootstrap_files_of_a_killed_job_are_polled_past(tmp_path, monkeypatch):
+    """with an explicit DQL_COMM_ID_FILE the name carries no job nonce.  Leftovers of a killed job — an old file, a file
+    of another job (other MASTER_PORT / world size), a stray `.done` marker — must not be taken for this job's."""
+    import threading
+    import time
+    from dql_multirotor_landing_amd import comm
+    monkeypatch.setenv("DQL_COMM_ID_FILE", str(tmp_path / "boot.id"))
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    f = tmp_path / "stale.bin"
+    f.write_bytes(comm._header(2) + b"x" * 64)
+    assert comm._read_fresh(f, 2, 64) == b"x" * 64
+    assert comm._read_fresh(f, 3, 64) is None                     # another world size
+    old = time.time() - 3600
+    os.utime(f, (old, old))
+    assert comm._read_fresh(f, 2, 64) is None                     # older than this process: a leftover
+    monkeypatch.setenv("MASTER_PORT", "29534")
+    f.write_bytes(comm._header(2) + b"x" * 64)
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    assert comm._read_fresh(f, 2, 64) is None                     # another job's port
+    f.write_bytes(b"x" * 64)
+    assert comm._read_fresh(f, 2, 64) is None                     # no header at all (what round 2 wrote)
+    # a full gather with leftovers of rank 1 in place: rank 0 must wait for the REAL rank 1
+    base = comm.id_file_path(0)
+    stale_bin = base.with_name(f"{base.stem}.t9.1.bin"); stale_done = base.with_name(f"{base.stem}.t9.1.done")
+    stale_bin.write_bytes(comm._header(2) + b"S" * 64); stale_done.write_bytes(comm._header(2))
+    os.utime(stale_bin, (old, old)); os.utime(stale_done, (old, old))
+    res = {}
+
+    def run(rank, delay):
+        time.sleep(delay)
+        res[rank] = comm.gather_via_files("t9", rank, 2, bytes([rank + 1]) * 64, timeout_s=30)
+
+    th = [threading.Thread(target=run, args=(0, 0.0)), threading.Thread(target=run, args=(1, 0.5))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert res[0] == res[1] == [bytes([1]) * 64, bytes([2]) * 64]

@@ -219,3 +219,59 @@ def test_trainer_resume_equals_uninterrupted_run(tmp_path, monkeypatch):
         assert json.loads(json.dumps(h_back)) == json.loads(json.dumps(h_full))
         for a, b in zip(back._engine.get_tables(), full._engine.get_tables()):
             np.testing.assert_array_equal(a, b)
+
+
+def test_checkpoint_files_carry_one_tag_and_a_mixed_checkpoint_is_not_resumed(tmp_path, monkeypatch):
+    """every file of a checkpoint is written as temp + replace, the env-state shard and trainer.json carry the same
+    (level, agent periods, chunk, world, generation) tag, and a shard that belongs to ANOTHER checkpoint (a rank killed between its
+    shard and rank 0's trainer.json, a leftover) is not flown: the level resumes from its tables, with a warning."""
+    import json
+    import shutil
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    kw = dict(curriculum_steps=2, n_envs=32, chunk_steps=8, checkpoint_every=2, max_num_episodes=60, t_max=3,
+              successive_successful_episodes=10, success_rate=0.25, mode="paper", judge_envs=16, eps_floor=0.3)
+
+    class Stop(Exception):
+        pass
+
+    run = tmp_path / "a" / "01-01-2026 10:00:00"
+    tr = T.Trainer(save_path=run, **kw)
+    saves = {"n": 0}
+    real_save = tr.save
+    def save_hook():
+        real_save()
+        if tr._progress is not None:
+            saves["n"] += 1
+            if saves["n"] == 1:
+                shutil.copy(run / "env_state_rank0.npz", tmp_path / "older_shard.npz")
+            if saves["n"] == 2:
+                raise Stop()
+    tr.save = save_hook
+    with pytest.raises(Stop):
+        tr.curriculum_training()
+    st = json.loads((run / "trainer.json").read_text())
+    z = np.load(run / "env_state_rank0.npz")
+    tag = st["progress"]["tag"]
+    assert {k: int(z["tag_" + k]) for k in tag} == tag and tag["world"] == 1 and tag["generation"] == 2 and tag["chunk_i"] == st["progress"]["chunk_i"]
+    assert not list(run.glob(".*tmp*")) and not list(tmp_path.glob("a/.*tmp*"))  # no temp file left behind
+    # the shard of the EARLIER checkpoint beside the newer trainer.json = what a kill between the two writes leaves
+    shutil.copy(tmp_path / "older_shard.npz", run / "env_state_rank0.npz")
+    back = T.Trainer.load(tmp_path / "a")
+    with pytest.warns(RuntimeWarning, match="belongs to checkpoint"):
+        hist = back.curriculum_training()
+    assert [h["level"] for h in hist][-1] == 1
+    # ... and a finished run loads as finished: curriculum_training() returns the stored history instead of asking for level 2 of 2
+    done = T.Trainer.load(tmp_path / "a")
+    assert done._working_curriculum_step == 2
+    assert _strip(done.curriculum_training()) == json.loads(json.dumps(_strip(hist)))
+
+
+def test_reducer_factory_without_sync_period_defaults_to_two(tmp_path, monkeypatch):
+    import dql_multirotor_landing_amd.trainer as T
+    from dql_multirotor_landing_amd.dist import LocalWindowReducer
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    tr = T.Trainer(save_path=tmp_path / "r", curriculum_steps=1, n_envs=16, chunk_steps=8, max_num_episodes=20, t_max=3, mode="paper",
+                   reducer_factory=LocalWindowReducer, checkpoint_every=10**9)
+    eng, runner = tr._make_engine(tr._config(0))
+    assert runner.sync_period == 2 and runner.reducer is not None

@@ -110,6 +110,7 @@ def test_plant_run_equals_oracle(ops):
     q = rng.normal(size=(ns, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
     init = np.c_[rng.uniform(-3, 3, (ns, 2)), rng.uniform(0.4, 4, (ns, 1)), rng.uniform(-2, 2, (ns, 3)), q, rng.uniform(-3, 3, (ns, 3)),
                  rng.uniform(0, 838, (ns, 4)), rng.uniform(-3, 3, (ns, 2)), rng.uniform(-1.6, 1.6, (ns, 2))]
+    init[:20, 0:2] = init[:20, 17:19] + rng.uniform(-0.3, 0.3, (20, 2)); init[:20, 2] = 0.5; init[:20, 3:6] = 0.0  # these start on the deck
     cmd = rng.uniform(0, 1000, (ns, nt, 4))
     for dtype in (F64, F32):
         cfg = DqlConfig(dtype=dtype)

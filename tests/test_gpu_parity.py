@@ -338,7 +338,7 @@ print("RANK_OK")
 """
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])  # 5 rank processes + this one: the GPU box admits 6 processes on its card
 def test_p2p_exchange_ranks_sharing_one_gpu_equal_one_process(tmp_path, world):
     """The one-shot peer-to-peer exchange (dql_p2p_*: HIP IPC mappings of uncached exchange buffers, flags with system-scope
     release / acquire, slots summed in rank order) with `world` rank PROCESSES — all on GPU 0, which is what a 1-GPU box can host; on a
@@ -392,8 +392,16 @@ eng.set_windowed(True)
 if rank == 0:
     eng.set_option("p2p_spin_limit", 200000)
     eng.train_steps(4, 1.0)
+    own = eng.get_accum()   # flushes: the window now holds this rank's own sums
     t0 = time.time(); red.all_reduce(); eng.sync(); dt = time.time() - t0
-    assert eng.p2p_failed(), "the wait must give up when the peer never pushes"
+    assert eng.p2p_failed() and eng.p2p_failed_seq() == 1, "the wait must give up when the peer never pushes, and say which exchange"
+    import numpy as np
+    assert np.array_equal(eng.get_accum(), own), "a given-up exchange must leave the window untouched (this rank's own sums), not half-summed"
+    try:  # the training loop's per-chunk synchronisation point: the run must END here, not carry on with diverging replicas
+        eng.stats()
+        raise SystemExit("stats() did not raise after a failed exchange")
+    except RuntimeError as e:
+        assert "gave up waiting for a peer" in str(e), str(e)
     print("GAVE_UP %.2f" % dt)
 else:
     time.sleep(6)   # connected, but never takes part in the exchange
@@ -403,7 +411,8 @@ else:
 
 def test_p2p_exchange_gives_up_on_a_missing_peer(tmp_path):
     """A rank whose peer never pushes: the wait kernel's poll loop is bounded (option "p2p_spin_limit"), every wave exits, the failure is
-    reported by dql_p2p_status — no hang, no GPU reset."""
+    reported by dql_p2p_status (with the number of the failed exchange) — no hang, no GPU reset; ONE waiter decides, so the window is
+    untouched rather than half-summed; and `stats()`, the Trainer's per-chunk synchronisation point, raises from then on."""
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
@@ -422,6 +431,111 @@ def test_p2p_exchange_gives_up_on_a_missing_peer(tmp_path):
     assert procs[0].returncode == 0 and "GAVE_UP" in outs[0][0], outs[0][0][-500:] + outs[0][1][-2000:]
     assert procs[1].returncode == 0 and "IDLE_OK" in outs[1][0], outs[1][1][-2000:]
     assert float(outs[0][0].split("GAVE_UP")[1].split()[0]) < 5.0
+
+
+def test_p2p_group_of_eight_ranks_in_one_process_equals_one_engine(mods):
+    """world = DQL_P2P_MAX_RANKS: eight ranks x 512 envs driven by ONE host thread (dist.ShardedGroup, buffers connected by pointer:
+    dql_p2p_connect_local; pushes of all ranks enqueued before any wait) on GPU 0 against one engine of 4 096 envs on the same windowed
+    schedule — slot layout [2 parities][8 ranks], the full flag array, parity flips over 41 exchanges: tables, counts, every env."""
+    from dql_multirotor_landing_amd.dist import LocalWindowReducer, ShardedGroup, ShardedRunner, shard_range
+    from dql_multirotor_landing_amd.engine import Engine
+    world, n_total = 8, 4096
+    engs = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        e = Engine(DqlConfig(dtype=F32, t_max=5.0), hi - lo, seed=42, env_id_offset=lo)
+        e.set_option("periods_per_launch", 2)
+        engs.append(e)
+    grp = ShardedGroup(engs, sync_period=2)
+    grp.train_steps(40, 1.0); grp.train_steps(41, 0.2); grp.sync()
+    single = Engine(DqlConfig(dtype=F32, t_max=5.0), n_total, seed=42)
+    single.set_option("periods_per_launch", 2)
+    run = ShardedRunner(single, LocalWindowReducer(single), sync_period=2)
+    run.train_steps(40, 1.0); run.train_steps(41, 0.2); run.sync()
+    qa, qb, cnt = single.get_tables()
+    assert cnt.sum() > 0
+    for e in engs:
+        assert not e.p2p_failed()
+        a, b, c = e.get_tables()
+        assert np.array_equal(a, qa) and np.array_equal(b, qb) and np.array_equal(c, cnt)
+    reals, ints = single.get_fields()
+    parts = [e.get_fields() for e in engs]
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), ints)
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), reals)
+    assert sum(e.stats()["decisions"] for e in engs) == single.stats()["decisions"]
+    for e in engs:
+        e.close()
+    single.close()
+
+
+@pytest.mark.parametrize("P,sync", [(1, None), (2, 4), (8, 8)])
+def test_engine_resume_equals_uninterrupted_run(mods, P, sync):
+    """get_fields + step_index -> fresh Engine -> set_tables + set_fields + set_step_index -> continue == the uninterrupted
+    run bit for bit (tables, every env, statistics), on the HIP engine, with several periods per launch (the ping-pong buffers follow
+    the launch parity, the tick schedule and the RNG counters the period index) and on the windowed schedule (base tables)."""
+    from dql_multirotor_landing_amd.dist import LocalWindowReducer, ShardedRunner
+    from dql_multirotor_landing_amd.engine import Engine
+    cfg = dict(dtype=F32, t_max=4.0, fold_per_step=1)
+    n = 1500
+
+    def make():
+        e = Engine(DqlConfig(**cfg), n, seed=9, env_id_offset=77)
+        e.set_option("periods_per_launch", P)
+        return e, ShardedRunner(e, LocalWindowReducer(e) if sync else None, sync_period=sync or 1)
+
+    k1, k2 = 40 + (3 if not sync else 0), 56   # (an odd number of launches before the checkpoint when the schedule allows it)
+    full, run = make()
+    run.train_steps(k1, 0.7); run.sync()
+    full.publish_tables()                      # a checkpoint is a table barrier in BOTH runs (Trainer.save)
+    s_mid = full.stats()
+    run.train_steps(k2, 0.3); run.sync()
+
+    part, run_p = make()
+    run_p.train_steps(k1, 0.7); run_p.sync()
+    part.publish_tables()
+    tabs, (reals, ints), j = part.get_tables(), part.get_fields(), part.step_index()
+    assert j == k1
+    part.close()
+    back, run_b = make()
+    back.set_tables(*tabs); back.set_fields(reals, ints); back.set_step_index(j)
+    assert back.step_index() == j and back.stats()["agent_steps"] == 0   # the statistics restart, the period index does not
+    run_b.train_steps(k2, 0.3); run_b.sync()
+    for a, b in zip(back.get_tables(), full.get_tables()):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(back.get_fields(), full.get_fields()):
+        np.testing.assert_array_equal(a, b)
+    s_full, s_back = full.stats(), back.stats()
+    assert s_back["agent_steps"] == k2 and s_full["agent_steps"] == k1 + k2
+    for key in ("decisions", "episodes"):
+        assert s_back[key] == s_full[key] - s_mid[key]
+    assert s_back["by_code"] == {c: s_full["by_code"][c] - s_mid["by_code"][c] for c in s_full["by_code"]}
+    full.close(); back.close()
+
+
+def test_step_dev_equals_step(mods):
+    """dql_step_dev (actions already in device memory, e.g. written by the caller's own policy kernel) == dql_step with the same actions
+    from the host: states, rewards, dones, every field."""
+    import ctypes as C
+    from dql_multirotor_landing_amd.engine import Engine
+    hip = C.CDLL("libamdhip64.so")
+    n = 777
+    a, b = Engine(DqlConfig(dtype=F32, t_max=3.0), n, seed=3), Engine(DqlConfig(dtype=F32, t_max=3.0), n, seed=3)
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(n)) == 0
+    rng = np.random.default_rng(0)
+    try:
+        for _ in range(90):
+            act = rng.integers(0, 3, n).astype(np.uint8)
+            a.step(act)
+            assert hip.hipMemcpy(dptr, act.ctypes.data_as(C.c_void_p), C.c_size_t(n), 1) == 0  # hipMemcpyHostToDevice
+            b.step_dev(dptr.value)
+        for x, y in zip(a.get_fields(), b.get_fields()):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a.rewards(), b.rewards())
+        assert a.stats()["episodes"] == b.stats()["episodes"] > 0
+    finally:
+        b.sync(); hip.hipFree(dptr)
+        a.close(); b.close()
 
 
 def test_bench_refuses_more_ranks_than_gpus():
