@@ -550,15 +550,19 @@ template <typename T> DQL_DEV void manager_states(const T (&R)[9], T cy, T sy, T
 }
 // manager_node.py:192-214 + observation_utils.py:77-158: relative observation, acceleration estimate, contact latch; THEN the
 // platform set-point of the next 10 ms
+// with_noise: the tick's noise draw is applied.  Inside the fused step only the LAST manager tick of an agent period needs it: the
+// noise sits on the published p / v only (the acceleration estimate runs on the clean velocity, G12), every tick overwrites the latched
+// observation, and the MDP reads the latch once, at the end of the period — so the draws of the earlier ticks (Philox + two Box-Muller
+// pairs each, ~1 300 instructions per period) are never consumed and are not made.  Same values, bit for bit, as drawing every tick.
 template <typename T>
 DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
-                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step) {
+                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, bool with_noise = true) {
   const T dxw = e.mp_x - e.p[0], dyw = e.mp_y - e.p[1];
   const T dvx = e.mp_u - e.v[0], dvy = e.mp_v - e.v[1];
   const T rpx = fma_(cy, dxw, sy * dyw), rpy = fma_(cy, dyw, -(sy * dxw));
   const T rvx = fma_(cy, dvx, sy * dvy), rvy = fma_(cy, dvy, -(sy * dvx));
   T opx = rpx, opy = rpy, ovx = rvx, ovy = rvy;
-  if (s.noise_p > T(0.0) || s.noise_v > T(0.0)) {
+  if (with_noise && (s.noise_p > T(0.0) || s.noise_v > T(0.0))) {
     uint32_t r[4]; T n0, n1, n2, n3;
     philox4x32(step_lo, step_hi, env_id, STREAM_NOISE0 + mgr_in_step, k0, k1, r);
     box_muller(r[0], r[1], n0, n1); box_muller(r[2], r[3], n2, n3);
@@ -980,10 +984,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   uint32_t mgr_in_step = 0;
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
+  // the period's last manager tick (wave-uniform): the only one whose observation noise is ever read (manager_obs)
+  const int first_mgr = phase ? s.div - phase : 0;
+  const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s.div) : 0u;
   auto manager_tick = [&]() {
     DQL_SECTION("manager");
     manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
-    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
+    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
     ++mgr_in_step; ++mgr_index;
   };
   auto control_and_plant = [&]() {
@@ -1018,7 +1025,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
           float Rm[9];  // scoped: a long-lived array would be demoted to LDS by the compiler
           rot_to_array(rp, Rm);
           manager_states(Rm, rp.cy, rp.sy, e.v[2], e.vz_state, e.yw_state);
-          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step);
+          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
           ++mgr_in_step; ++mgr_index;
         }
         ts.pid_state = mk2(e.vz_state, e.yw_state); ts.mp_xy = mk2(e.mp_x, e.mp_y); ts.mp_uv = mk2(e.mp_u, e.mp_v);

@@ -52,7 +52,7 @@ class Engine:
         a = np.ascontiguousarray(actions, dtype=np.uint8)
         if a.shape != (self.n,):
             raise ValueError(f"actions must have shape ({self.n},)")
-        if ((a & 3) > 2).any() or (a >> 4).any() or (((a >> 2) & 3) > 2).any():
+        if (a > 10).any() or ((a & 3) > 2).any():  # ax | ay << 2 with ax, ay in 0..2: at most 2 | 2 << 2 = 10 (the kernel checks again, per env)
             raise ValueError("actions must be ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold)")
         _lib.check(self.lib.dql_step(self._h, _p(a)))
 
@@ -111,12 +111,15 @@ class Engine:
 
     def step_outputs(self):
         """what `TrainingLandingEnv.step` returns, for every env, in one device round trip (include/dql.h dql_step_outputs):
-        dict of arrays idx_x, idx_y, reward, done, code, step_count, cumulative_reward, was_reset"""
-        n = self.n
-        o = {"idx_x": np.zeros(n, np.int32), "idx_y": np.zeros(n, np.int32), "reward": np.zeros(n, np.float64), "done": np.zeros(n, np.uint8),
-             "code": np.zeros(n, np.int8), "step_count": np.zeros(n, np.int32), "cumulative_reward": np.zeros(n, np.float64), "was_reset": np.zeros(n, np.uint8)}
-        _lib.check(self.lib.dql_step_outputs(self._h, *[_p(o[k]) for k in ("idx_x", "idx_y", "reward", "done", "code", "step_count", "cumulative_reward", "was_reset")]))
-        return o
+        dict of arrays idx_x, idx_y, reward, done, code, step_count, cumulative_reward, was_reset (fresh copies of the engine's buffers)"""
+        so = self.__dict__.get("_so")
+        if so is None:  # output arrays and their pointers: made once
+            n = self.n
+            o = {"idx_x": np.zeros(n, np.int32), "idx_y": np.zeros(n, np.int32), "reward": np.zeros(n, np.float64), "done": np.zeros(n, np.uint8),
+                 "code": np.zeros(n, np.int8), "step_count": np.zeros(n, np.int32), "cumulative_reward": np.zeros(n, np.float64), "was_reset": np.zeros(n, np.uint8)}
+            so = self._so = (o, [_p(o[k]) for k in ("idx_x", "idx_y", "reward", "done", "code", "step_count", "cumulative_reward", "was_reset")])
+        _lib.check(self.lib.dql_step_outputs(self._h, *so[1]))
+        return {k: v.copy() for k, v in so[0].items()}
 
     def get_fields(self):
         nr, ni = self.n_fields()

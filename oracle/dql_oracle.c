@@ -590,8 +590,14 @@ static inline void platform_update(const simc_t* s, env_t* e) {
 /* scripts/manager_node.py:192-214 + pkg/observation_utils.py:77-158: relative state in the yaw-only frame, PID
  * inputs, acceleration estimate; THEN the platform set-point for the next 10 ms (the observation uses the platform
  * state Gazebo reported before this tick's set_model_state) */
+/* with_noise: apply this tick's noise draw.  The noise sits on the published p / v only, every tick overwrites the latched
+ * Observation and the MDP reads the latch once per agent period, so inside the fused step only the period's LAST manager tick needs
+ * its draw; the others are skipped (same values, bit for bit: tests/test_oracle_golden.py::test_lazy_noise_equals_eager_noise pins
+ * it against drawing every tick, orc_set_eager_noise) */
+static int g_eager_noise = 0;
+EXPORT void ORC(set_eager_noise)(int on) { g_eager_noise = on; }
 static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL cy, REAL sy, int64_t mgr_index,
-                                uint32_t k0, uint32_t k1, uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step) {
+                                uint32_t k0, uint32_t k1, uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, int with_noise) {
   const REAL dxw = e->mp_x - e->p[0], dyw = e->mp_y - e->p[1];
   const REAL dvx = e->mp_u - e->v[0], dvy = e->mp_v - e->v[1];
   const REAL rpx = FMA(cy, dxw, sy * dyw), rpy = FMA(cy, dyw, -(sy * dxw));
@@ -605,7 +611,7 @@ static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL
     e->yaw.state = det_atan2(FMA(A10, cy, A11 * sy), FMA(A00, cy, A01 * sy));
   }
   REAL opx = rpx, opy = rpy, ovx = rvx, ovy = rvy;
-  if (s->noise_p > R_(0.0) || s->noise_v > R_(0.0)) { /* pkg/observation_utils.py:127-128 */
+  if (with_noise && (s->noise_p > R_(0.0) || s->noise_v > R_(0.0))) { /* pkg/observation_utils.py:127-128 */
     uint32_t r[4]; REAL n0, n1, n2, n3;
     philox4x32(step_lo, step_hi, env_id, STREAM_NOISE0 + mgr_in_step, k0, k1, r);
     box_muller(r[0], r[1], &n0, &n1); box_muller(r[2], r[3], &n2, &n3);
@@ -701,10 +707,12 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
   REAL R[9], cy, sy;
   uint32_t mgr_in_step = 0;
+  const int phase0 = (int)(g0 % s->div), first_mgr = phase0 ? s->div - phase0 : 0;
+  const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s->div) : 0u; /* the period's last manager tick */
   for (int i = 0; i < n_ticks; ++i) {
     const int64_t g = g0 + i;
     quat_to_R(e->q, R); yaw_cs(R, &cy, &sy);
-    if (g % s->div == 0) { manager_tick(s, e, R, cy, sy, g / s->div, k0, k1, step_lo, step_hi, env_id, mgr_in_step); ++mgr_in_step; }
+    if (g % s->div == 0) { manager_tick(s, e, R, cy, sy, g / s->div, k0, k1, step_lo, step_hi, env_id, mgr_in_step, g_eager_noise || mgr_in_step == last_mgr); ++mgr_in_step; }
     const REAL thrust = pid_output(&s->pvz, &s->bw, &e->vz, s->dt);
     const REAL r_cmd = pid_output(&s->pyaw, &s->bw, &e->yaw, s->dt);
     REAL cmd[4], M[3];
@@ -962,7 +970,7 @@ EXPORT void ORC(manager_run)(const dql_config* c, int64_t n_ticks, const double*
     if (contact[t]) e.flags |= FL_CONTACT;
     REAL R[9], cy, sy;
     quat_to_R(e.q, R); yaw_cs(R, &cy, &sy);
-    manager_tick(&s, &e, R, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, 0u, (uint32_t)t);
+    manager_tick(&s, &e, R, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, 0u, (uint32_t)t, 1);
     double* o = out + t * 12;
     o[0] = e.obs[0]; o[1] = e.obs[1]; o[2] = e.obs[2]; o[3] = e.obs[3]; o[4] = e.obs[4]; o[5] = e.obs[5];
     o[6] = e.vz.state; o[7] = e.yaw.state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;

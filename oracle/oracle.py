@@ -171,6 +171,8 @@ class Oracle:
     def set_option(self, name, value):
         if name == "periods_per_launch":
             self.periods_per_launch = int(value)
+        if name == "eager_noise":  # process-wide debug switch: draw the observation noise at EVERY manager tick (what the lazy form must equal)
+            lib().orc_f32_set_eager_noise(C.c_int(int(value))); lib().orc_f64_set_eager_noise(C.c_int(int(value)))
 
     def _period(self, mode, eps=0.0, actions=None, n_periods=1):
         """one LAUNCH of n_periods agent periods: same acting tables, one set of accumulators"""

@@ -337,3 +337,29 @@ def test_g13_simulation_env_y_state(golden_dir):
     idx = orc.discretise(DqlConfig(dtype=F64, working_curriculum_step=4), obs[:, 1], obs[:, 3], obs[:, 5], roll)
     sy = rows[:, 7:12].astype(int)
     np.testing.assert_array_equal(idx, (((sy[:, 0] * 3 + sy[:, 1]) * 3 + sy[:, 2]) * 3 + sy[:, 3]) * 7 + sy[:, 4])
+
+
+def test_lazy_noise_equals_eager_noise():
+    """Round 3 shortens the fused step by drawing the observation noise only at the LAST manager tick of an agent period (the only
+    draw the MDP ever reads: the noise sits on the latched p / v, which every manager tick overwrites).  Pinned here against drawing
+    at every tick, in both dtypes, with periods of 21 and 22 ticks and 4 or 5 manager ticks: every field, the tables and the counters."""
+    from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
+    from oracle.oracle import Oracle
+    for dtype in (F32, F64):
+        kw = dict(dtype=dtype, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, t_max=4.0)
+        lazy, eager = Oracle(DqlConfig(**kw), 96, seed=5), Oracle(DqlConfig(**kw), 96, seed=5)
+        try:
+            eager.set_option("eager_noise", 1)
+            eager.train_steps(60, 0.6)
+            eager.set_option("eager_noise", 0)
+            lazy.train_steps(60, 0.6)
+        finally:
+            eager.set_option("eager_noise", 0)
+        for a, b in zip(lazy.get_fields(), eager.get_fields()):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(lazy.qa, eager.qa)
+        np.testing.assert_array_equal(lazy.count, eager.count)
+        assert lazy.stats_dict() == eager.stats_dict() and lazy.stats_dict()["episodes"] > 0
+        reals, _ = lazy.get_fields()
+        names = lazy.field_names()
+        assert np.abs(reals[names.index("obs_p_x")] - (reals[names.index("mp_x")] - reals[names.index("px")])).max() > 0.05  # the noise is there
