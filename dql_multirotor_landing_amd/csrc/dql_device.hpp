@@ -203,6 +203,7 @@ template <typename T> struct MdpK {
 // SimK: constants of the physics tick loop (kernel argument by value).
 template <typename T> struct SimK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
+  T dtm, dtg, dtI[3];  // dt / m, dt g, dt / I: the float32 tick integrates with them (one fma per component, see FAST32)
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -220,6 +221,7 @@ template <typename T> struct SimK {
 DQL_DEV float to_vgpr(float x) { float y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 template <typename T> struct HotK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, lkf, kmkf, aup, adn, omax, cd, crd;
+  T dtm, dtg, dtI[3];
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -230,6 +232,7 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   HotK<float> h;
 #define DQL_HOT(f) h.f = to_vgpr(s.f)
   DQL_HOT(dt); DQL_HOT(g); DQL_HOT(inv_m); DQL_HOT(I[0]); DQL_HOT(I[1]); DQL_HOT(I[2]); DQL_HOT(inv_I[0]); DQL_HOT(inv_I[1]); DQL_HOT(inv_I[2]);
+  DQL_HOT(dtm); DQL_HOT(dtg); DQL_HOT(dtI[0]); DQL_HOT(dtI[1]); DQL_HOT(dtI[2]);
   DQL_HOT(l); DQL_HOT(h); DQL_HOT(kf); DQL_HOT(lkf); DQL_HOT(kmkf); DQL_HOT(aup); DQL_HOT(adn); DQL_HOT(omax); DQL_HOT(cd); DQL_HOT(crd);
   DQL_HOT(kR[0]); DQL_HOT(kR[1]); DQL_HOT(kR[2]); DQL_HOT(kW[0]); DQL_HOT(kW[1]); DQL_HOT(kW[2]); DQL_HOT(ia); DQL_HOT(ib); DQL_HOT(ic);
   DQL_HOT(vz_kp); DQL_HOT(vz_ki); DQL_HOT(vz_lo); DQL_HOT(vz_hi); DQL_HOT(vz_wind); DQL_HOT(vz_sp);
@@ -401,8 +404,18 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // ---------------------------------------------------------------------------------------------
 // filters / PID  (pkg/filters.py, pkg/pid.py)
 // ---------------------------------------------------------------------------------------------
+// FLOAT32 TICK, ROUND 3.  The float64 instantiation spells the reference's expressions out operation by operation (it is what the golden
+// vectors pin and what the recorded flights of tests/golden were flown with).  The float32 instantiation — the one every throughput
+// figure is measured on — is bound by VALU issue, so it takes the same formulas in their shortest correctly-rounded-per-operation form:
+// products folded into the additions that consume them (fma), the integration constants dt/m, dt g, dt/I multiplied out on the host,
+// two Newton steps from a second-order start for the yaw frame's normalisation.  ~27 of a tick's ~360 instructions.  The oracle's float32
+// build (oracle/dql_oracle.c, ORACLE_F32) spells out the same sequence, so float32 parity stays bit for bit; float32 against float64 stays
+// within the north_star tolerance (tests/test_gpu_parity.py::test_f32_kernel_vs_f64_oracle_one_period).
+template <typename T> struct Fast32 { static constexpr bool on = sizeof(T) == 4; };
 template <typename T, typename K> DQL_DEV T butterworth(const K& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
-  T acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
+  T acc;
+  if constexpr (Fast32<T>::on) acc = fma_(-T(c.bw_k1), y3, fma_(T(2.0), x1, x2) + x0);
+  else acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
   if (c.bw_k2 != 0) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
   const T value = c.bw_inv * acc;
   x2 = x1; x1 = x0;
@@ -413,9 +426,11 @@ template <typename T, typename K>
 DQL_DEV T pid_output(const K& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, T& integ, T& x1, T& x2, T& y1, T& y2, T& y3) {
   // pid.py:62-104 with Kd = 0 (launch/drone.launch:37,51; dql_create rejects Kd != 0)
   const T e0 = sp - state;
-  integ = clip3(integ + e0 * c.dt, -wind, wind);
+  if constexpr (Fast32<T>::on) integ = clip3(fma_(e0, T(c.dt), integ), -wind, wind);
+  else integ = clip3(integ + e0 * c.dt, -wind, wind);
   const T fe = butterworth(c, e0, x1, x2, y1, y2, y3);
-  return clip3(kp * fe + ki * integ, lo, hi);
+  if constexpr (Fast32<T>::on) return clip3(fma_(kp, fe, ki * integ), lo, hi);
+  else return clip3(kp * fe + ki * integ, lo, hi);
 }
 template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z) {  // filters.py:19-36
   P += Q;
@@ -446,12 +461,24 @@ template <typename T> DQL_DEV void quat_to_R(const T (&q)[4], T (&R)[9]) {
 template <typename T> struct YawIters;
 template <> struct YawIters<float> { static constexpr int n = 4; };
 template <> struct YawIters<double> { static constexpr int n = 5; };
-template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
-  const T n2 = fma_(R[0], R[0], R[3] * R[3]);
+// float32 (FAST32): second-order start 1 + d/2 + 3 d^2 / 8, d = 1 - n2 (error 5 d^3 / 16), then TWO Newton steps: 2e-9 at a tilt of 30 deg
+template <typename T> DQL_DEV T yaw_rnorm(T n2) {
   const T h = T(-0.5) * n2;
-  T r = fma_(T(-0.5), n2, T(1.5));
+  T r;
+  if constexpr (Fast32<T>::on) {
+    const T d = T(1.0) - n2;
+    r = fma_(fma_(T(0.375), d, T(0.5)), d, T(1.0));
 #pragma unroll
-  for (int k = 0; k < YawIters<T>::n; ++k) r = r * fma_(h * r, r, T(1.5));
+    for (int k = 0; k < 2; ++k) r = r * fma_(h * r, r, T(1.5));
+  } else {
+    r = fma_(T(-0.5), n2, T(1.5));
+#pragma unroll
+    for (int k = 0; k < YawIters<T>::n; ++k) r = r * fma_(h * r, r, T(1.5));
+  }
+  return r;
+}
+template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
+  const T r = yaw_rnorm(fma_(R[0], R[0], R[3] * R[3]));
   c = R[0] * r; s = R[3] * r;
 }
 // attitude_controller.py:107-156
@@ -464,14 +491,25 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
   const T E01 = DQL_E(0, 1), E10 = DQL_E(1, 0), E02 = DQL_E(0, 2), E20 = DQL_E(2, 0), E12 = DQL_E(1, 2), E21 = DQL_E(2, 1), E22 = DQL_E(2, 2);
 #undef DQL_E
   const T eR0 = T(0.5) * (E21 - E12), eR1 = T(0.5) * (E02 - E20), eR2 = T(0.5) * (E10 - E01);
-  const T eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
-  const T M0 = -(eR0 * s.kR[0]) - eW0 * s.kW[0];
-  const T M1 = -(eR1 * s.kR[1]) - eW1 * s.kW[1];
-  const T M2 = -(eR2 * s.kR[2]) - eW2 * s.kW[2];
-  const T a = thrust * s.ia, bx = M0 * s.ib, by = M1 * s.ib, cz = M2 * s.ic;
-  const T w2[4] = {a - by + cz, a + bx - cz, a + by + cz, a - bx - cz};
+  if constexpr (Fast32<T>::on) {
+    const T eW0 = fma_(-r_cmd, E02, w[0]), eW1 = fma_(-r_cmd, E12, w[1]), eW2 = fma_(-r_cmd, E22, w[2]);
+    const T M0 = fma_(-eW0, T(s.kW[0]), -(eR0 * s.kR[0]));
+    const T M1 = fma_(-eW1, T(s.kW[1]), -(eR1 * s.kR[1]));
+    const T M2 = fma_(-eW2, T(s.kW[2]), -(eR2 * s.kR[2]));
+    const T a = thrust * s.ia;
+    const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
+    for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
+  } else {
+    const T eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
+    const T M0 = -(eR0 * s.kR[0]) - eW0 * s.kW[0];
+    const T M1 = -(eR1 * s.kR[1]) - eW1 * s.kW[1];
+    const T M2 = -(eR2 * s.kR[2]) - eW2 * s.kW[2];
+    const T a = thrust * s.ia, bx = M0 * s.ib, by = M1 * s.ib, cz = M2 * s.ic;
+    const T w2[4] = {a - by + cz, a + bx - cz, a + by + cz, a - bx - cz};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
+  }
 }
 // gazebo_motor_model.cpp:434-500 + semi-implicit Euler of one rigid body
 // first-order rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364)
@@ -502,16 +540,23 @@ template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e,
   const T tzd = -(s.cd * fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))));  // sum_i (r_i x drag_i)_z / l
   tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, tzd, tz);
   tx = fma_(s.crd, Fbx, tx); ty = fma_(s.crd, Fby, ty);  // rolling moment = (c_r / c_d) * drag force
-  const T ax = fma_(R[0], Fbx, fma_(R[1], Fby, R[2] * Fbz)) * s.inv_m;
-  const T ay = fma_(R[3], Fbx, fma_(R[4], Fby, R[5] * Fbz)) * s.inv_m;
-  const T az = fma_(R[6], Fbx, fma_(R[7], Fby, R[8] * Fbz)) * s.inv_m - s.g;
-  e.v[0] = fma_(s.dt, ax, e.v[0]); e.v[1] = fma_(s.dt, ay, e.v[1]); e.v[2] = fma_(s.dt, az, e.v[2]);
+  const T Fwx = fma_(R[0], Fbx, fma_(R[1], Fby, R[2] * Fbz)), Fwy = fma_(R[3], Fbx, fma_(R[4], Fby, R[5] * Fbz)), Fwz = fma_(R[6], Fbx, fma_(R[7], Fby, R[8] * Fbz));
+  if constexpr (Fast32<T>::on) {
+    e.v[0] = fma_(T(s.dtm), Fwx, e.v[0]); e.v[1] = fma_(T(s.dtm), Fwy, e.v[1]); e.v[2] = fma_(T(s.dtm), Fwz, e.v[2]) - s.dtg;
+  } else {
+    const T ax = Fwx * s.inv_m, ay = Fwy * s.inv_m, az = Fwz * s.inv_m - s.g;
+    e.v[0] = fma_(s.dt, ax, e.v[0]); e.v[1] = fma_(s.dt, ay, e.v[1]); e.v[2] = fma_(s.dt, az, e.v[2]);
+  }
   e.p[0] = fma_(s.dt, e.v[0], e.p[0]); e.p[1] = fma_(s.dt, e.v[1], e.p[1]); e.p[2] = fma_(s.dt, e.v[2], e.p[2]);
   const T Iw0 = s.I[0] * w0, Iw1 = s.I[1] * w1, Iw2 = s.I[2] * w2;
   const T g0 = fma_(w1, Iw2, -(w2 * Iw1)), g1 = fma_(w2, Iw0, -(w0 * Iw2)), g2 = fma_(w0, Iw1, -(w1 * Iw0));
-  e.w[0] = fma_(s.dt, (tx - g0) * s.inv_I[0], w0);
-  e.w[1] = fma_(s.dt, (ty - g1) * s.inv_I[1], w1);
-  e.w[2] = fma_(s.dt, (tz - g2) * s.inv_I[2], w2);
+  if constexpr (Fast32<T>::on) {
+    e.w[0] = fma_(T(s.dtI[0]), tx - g0, w0); e.w[1] = fma_(T(s.dtI[1]), ty - g1, w1); e.w[2] = fma_(T(s.dtI[2]), tz - g2, w2);
+  } else {
+    e.w[0] = fma_(s.dt, (tx - g0) * s.inv_I[0], w0);
+    e.w[1] = fma_(s.dt, (ty - g1) * s.inv_I[1], w1);
+    e.w[2] = fma_(s.dt, (tz - g2) * s.inv_I[2], w2);
+  }
   const T qw = e.q[0], qx = e.q[1], qy = e.q[2], qz = e.q[3], hdt = T(0.5) * s.dt;
   const T dw = -fma_(qx, e.w[0], fma_(qy, e.w[1], qz * e.w[2]));
   const T dxq = fma_(qw, e.w[0], fma_(qy, e.w[2], -(qz * e.w[1])));
@@ -678,11 +723,7 @@ DQL_DEV void rot_pk(const TickPk& s, RotPk& r) {
   r.R57 = bc2(2.0f) * pfma(lo2(wx_wy), f2{-1.0f, 1.0f}, hi2(xz_yz));    // 2 (yz - wx), 2 (yz + wx)
   r.R01 = f2{r.R04.x, r.R13.x}; r.R34 = f2{r.R13.y, r.R04.y}; r.R67 = f2{r.R26.y, r.R57.y};
   const float R0 = r.R04.x, R3 = r.R13.y;
-  const float n2 = fma_(R0, R0, R3 * R3);
-  const float h = -0.5f * n2;
-  float rr = fma_(-0.5f, n2, 1.5f);
-#pragma unroll
-  for (int k = 0; k < YawIters<float>::n; ++k) rr = rr * fma_(h * rr, rr, 1.5f);
+  const float rr = yaw_rnorm(fma_(R0, R0, R3 * R3));
   r.cy = R0 * rr; r.sy = R3 * rr;
 }
 DQL_DEV void rot_to_array(const RotPk& r, float (&R)[9]) {
@@ -691,13 +732,13 @@ DQL_DEV void rot_to_array(const RotPk& r, float (&R)[9]) {
 // constants of the packed tick (register pairs), built once per agent period
 struct PkK {
   f2 kp, ki, lo, hi, wind, sp;     // the two PIDs: (v_z, yaw)
-  f2 kRn, kW01, I01, invI01;       // kRn = (kR0, -kR1)
+  f2 kRn, kW01, I01, dtI01;        // kRn = (kR0, -kR1)
 };
 template <typename K> DQL_DEV PkK make_pkk(const K& c) {
   PkK k;
   k.kp = mk2(c.vz_kp, c.yw_kp); k.ki = mk2(c.vz_ki, c.yw_ki); k.lo = mk2(c.vz_lo, c.yw_lo); k.hi = mk2(c.vz_hi, c.yw_hi);
   k.wind = mk2(c.vz_wind, c.yw_wind); k.sp = mk2(c.vz_sp, c.yw_sp);
-  k.kRn = mk2(c.kR[0], -c.kR[1]); k.kW01 = mk2(c.kW[0], c.kW[1]); k.I01 = mk2(c.I[0], c.I[1]); k.invI01 = mk2(c.inv_I[0], c.inv_I[1]);
+  k.kRn = mk2(c.kR[0], -c.kR[1]); k.kW01 = mk2(c.kW[0], c.kW[1]); k.I01 = mk2(c.I[0], c.I[1]); k.dtI01 = mk2(c.dtI[0], c.dtI[1]);
   return k;
 }
 // one 500 Hz physics tick after the rotation (and the manager tick, if due): both PIDs, attitude law, rotor model, rigid body,
@@ -707,13 +748,13 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
                              const float B5, const float B8, int& flags) {
   // ---- pid_output x 2 (pid.py:62-104, Kd = 0) ----
   const f2 e0 = k.sp - s.pid_state;
-  const f2 ii = s.pid_i + e0 * bc2(c.dt);
+  const f2 ii = pfma(e0, bc2(c.dt), s.pid_i);
   s.pid_i = f2{clip3(ii.x, -k.wind.x, k.wind.x), clip3(ii.y, -k.wind.y, k.wind.y)};
-  f2 acc = s.pid_x2 + bc2(2.0f) * s.pid_x1 + e0 - bc2(c.bw_k1) * s.pid_y3;
+  f2 acc = pfma(-bc2(c.bw_k1), s.pid_y3, pfma(bc2(2.0f), s.pid_x1, s.pid_x2) + e0);
   if (c.bw_k2 != 0) acc = acc - (bc2(c.bw_k2) * s.pid_y2);
   const f2 fe = bc2(c.bw_inv) * acc;
   s.pid_x2 = s.pid_x1; s.pid_x1 = e0; s.pid_y3 = s.pid_y2; s.pid_y2 = s.pid_y1; s.pid_y1 = fe;
-  const f2 eff = k.kp * fe + k.ki * s.pid_i;
+  const f2 eff = pfma(k.kp, fe, k.ki * s.pid_i);
   const float thrust = clip3(eff.x, k.lo.x, k.hi.x), r_cmd = clip3(eff.y, k.lo.y, k.hi.y);
   // ---- attitude law (attitude_controller.py:107-156) ----
   const f2 cy2 = bc2(r.cy), sy2 = bc2(r.sy);
@@ -729,14 +770,14 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const float E22 = fma_(D25.x, r.R26.x, fma_(D25.y, r.R57.x, D8 * r.R8));
   const f2 hh = bc2(0.5f) * (E02_12 - E20_21);                              // (eR1, -eR0)
   const float eR2 = 0.5f * (E01_10.y - E01_10.x);
-  const f2 eW01 = s.w01 - bc2(r_cmd) * E02_12;
-  const float eW2 = s.w2 - r_cmd * E22;
-  const f2 M01 = swp2(hh) * k.kRn - eW01 * k.kW01;                          // (-(eR0 kR0) - eW0 kW0, -(eR1 kR1) - eW1 kW1)
-  const float M2 = -(eR2 * c.kR[2]) - eW2 * c.kW[2];
-  const float a = thrust * c.ia, cz = M2 * c.ic;
-  const f2 bxy = M01 * bc2(c.ib);
-  const f2 w2_02 = pfma(hi2(bxy), f2{-1.0f, 1.0f}, bc2(a)) + bc2(cz);      // (a - by) + cz, (a + by) + cz
-  const f2 w2_13 = pfma(lo2(bxy), f2{1.0f, -1.0f}, bc2(a)) - bc2(cz);      // (a + bx) - cz, (a - bx) - cz
+  const f2 eW01 = pfma(-bc2(r_cmd), E02_12, s.w01);
+  const float eW2 = fma_(-r_cmd, E22, s.w2);
+  const f2 M01 = pfma(-eW01, k.kW01, swp2(hh) * k.kRn);                     // fma(-eW0, kW0, -(eR0 kR0)), fma(-eW1, kW1, -(eR1 kR1))
+  const float M2 = fma_(-eW2, (float)c.kW[2], -(eR2 * c.kR[2]));
+  const float a = thrust * c.ia;
+  const f2 ibn = f2{-(float)c.ib, (float)c.ib};
+  const f2 w2_02 = pfma(bc2(M2), bc2((float)c.ic), pfma(hi2(M01), ibn, bc2(a)));          // fma(M2, ic, fma(-+M1, ib, a))
+  const f2 w2_13 = pfma(bc2(M2), bc2(-(float)c.ic), pfma(lo2(M01), swp2(ibn), bc2(a)));   // fma(-M2, ic, fma(+-M0, ib, a))
   const f2 cmd02 = f2{sqrt_(w2_02.x > 0.0f ? w2_02.x : 0.0f), sqrt_(w2_02.y > 0.0f ? w2_02.y : 0.0f)};
   const f2 cmd13 = f2{sqrt_(w2_13.x > 0.0f ? w2_13.x : 0.0f), sqrt_(w2_13.y > 0.0f ? w2_13.y : 0.0f)};
   // ---- rotor forces from the CURRENT rotor speeds + rigid body (gazebo_motor_model.cpp:434-500) ----
@@ -757,16 +798,16 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const float tzd = -(c.cd * fma_(u.y, d02, fma_(wzl, S, -(u.x * d13))));
   txy = pfma(f2{-h, h}, swp2(F), txy); tz = fma_(l, tzd, tz);
   txy = pfma(bc2(c.crd), F, txy);
-  const float ax = fma_(r.R04.x, F.x, fma_(r.R13.x, F.y, r.R26.x * Fbz)) * c.inv_m;
-  const float ay = fma_(r.R13.y, F.x, fma_(r.R04.y, F.y, r.R57.x * Fbz)) * c.inv_m;
-  const float az = fma_(r.R26.y, F.x, fma_(r.R57.y, F.y, r.R8 * Fbz)) * c.inv_m - c.g;
-  s.v01 = pfma(bc2(c.dt), f2{ax, ay}, s.v01); s.v2 = fma_(c.dt, az, s.v2);
+  const float Fwx = fma_(r.R04.x, F.x, fma_(r.R13.x, F.y, r.R26.x * Fbz));
+  const float Fwy = fma_(r.R13.y, F.x, fma_(r.R04.y, F.y, r.R57.x * Fbz));
+  const float Fwz = fma_(r.R26.y, F.x, fma_(r.R57.y, F.y, r.R8 * Fbz));
+  s.v01 = pfma(bc2((float)c.dtm), f2{Fwx, Fwy}, s.v01); s.v2 = fma_((float)c.dtm, Fwz, s.v2) - c.dtg;
   s.p01 = pfma(bc2(c.dt), s.v01, s.p01); s.p2 = fma_(c.dt, s.v2, s.p2);
   const float w0 = s.w01.x, w1 = s.w01.y, w2 = s.w2;
   const f2 Iw01 = k.I01 * s.w01; const float Iw2 = c.I[2] * w2;
   const float g0 = fma_(w1, Iw2, -(w2 * Iw01.y)), g1 = fma_(w2, Iw01.x, -(w0 * Iw2)), g2 = fma_(w0, Iw01.y, -(w1 * Iw01.x));
-  s.w01 = pfma(bc2(c.dt), (txy - f2{g0, g1}) * k.invI01, s.w01);
-  s.w2 = fma_(c.dt, (tz - g2) * c.inv_I[2], w2);
+  s.w01 = pfma(k.dtI01, txy - f2{g0, g1}, s.w01);
+  s.w2 = fma_((float)c.dtI[2], tz - g2, w2);
   {
     const float qw = s.q_wx.x, qx = s.q_wx.y, qy = s.q_yz.x, qz = s.q_yz.y, hdt = 0.5f * c.dt;
     const float nw0 = s.w01.x, nw1 = s.w01.y, nw2 = s.w2;

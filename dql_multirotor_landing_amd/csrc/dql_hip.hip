@@ -76,6 +76,8 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   SimK<T> d;
   memset(&d, 0, sizeof(d));
   d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
+  d.dtm = (T)(c.dt / c.mass); d.dtg = (T)(c.dt * c.gravity);
+  for (int i = 0; i < 3; ++i) d.dtI[i] = (T)(c.dt / c.inertia[i]);
   for (int i = 0; i < 3; ++i) { d.I[i] = (T)c.inertia[i]; d.inv_I[i] = (T)(1.0 / c.inertia[i]); d.kR[i] = (T)c.k_R[i]; d.kW[i] = (T)c.k_W[i]; }
   d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m; d.lkf = (T)(c.arm_length * c.k_f); d.kmkf = (T)(c.k_m * c.k_f);
   d.aup = (T)c.rotor_alpha_up; d.adn = (T)c.rotor_alpha_down; d.omax = (T)c.rotor_max; d.cd = (T)c.c_drag; d.crd = (T)(c.c_roll / c.c_drag);
@@ -180,7 +182,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
   return q;
 }
 
-#define DQL_MAX_PERIODS 8  // agent periods one launch may run back to back per env (option "periods_per_launch")
+#define DQL_MAX_PERIODS 16  // agent periods one launch may run back to back per env (option "periods_per_launch")
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T>* mdp;
@@ -222,26 +224,23 @@ DQL_DEV long long wave_sum(long long v) {
 // first; the later loads then hit the scalar cache.
 template <int BYTES> DQL_DEV void warm_kernarg() {
   const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
-  unsigned t0, t1, t2, t3, t4, t5, t6, t7;
-  asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
-               "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+  constexpr int L = (BYTES + 63) / 64;  // 64-byte lines the arguments reach (9 .. 16); offsets beyond the last line fold back onto it
+  static_assert(L > 8 && L <= 16, "adjust the touch list to the argument size");
+#define DQL_LINE(i) ((i) < L ? (i) * 64 : (L - 1) * 64)
+  unsigned t0, t1, t2, t3, t4, t5, t6, t7, u0, u1, u2, u3, u4, u5, u6, u7;
+  // sixteen loads in flight, one wait.  The first statement's destinations are inputs of the second, so the compiler keeps them allocated
+  // until the wait (a register handed to another value while a load into it is still in flight would be overwritten when it lands)
+  asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
+               "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16"
+               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+               : "s"(p), "n"(DQL_LINE(0)), "n"(DQL_LINE(1)), "n"(DQL_LINE(2)), "n"(DQL_LINE(3)), "n"(DQL_LINE(4)), "n"(DQL_LINE(5)), "n"(DQL_LINE(6)), "n"(DQL_LINE(7)));
+  asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
+               "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\t"
                "s_waitcnt lgkmcnt(0)"
-               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(p));
-  // the remaining lines, only those the arguments reach; loads and their wait stay inside ONE asm statement (the compiler must
-  // not reuse a destination register while a load into it is still in flight)
-  static_assert(BYTES > 0x200 && BYTES <= 0x380 && !(BYTES > 0x280 && BYTES <= 0x300), "adjust the touch list to the argument size");
-  if constexpr (BYTES <= 0x240)
-    asm volatile("s_load_dword %0, %1, 0x200\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0) : "s"(p));
-  else if constexpr (BYTES <= 0x280)
-    asm volatile("s_load_dword %0, %2, 0x200\n\ts_load_dword %1, %2, 0x240\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1) : "s"(p));
-  else if constexpr (BYTES <= 0x340)
-    asm volatile("s_load_dword %0, %5, 0x200\n\ts_load_dword %1, %5, 0x240\n\ts_load_dword %2, %5, 0x280\n\ts_load_dword %3, %5, 0x2c0\n\t"
-                 "s_load_dword %4, %5, 0x300\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) : "s"(p));
-  else
-    asm volatile("s_load_dword %0, %6, 0x200\n\ts_load_dword %1, %6, 0x240\n\ts_load_dword %2, %6, 0x280\n\ts_load_dword %3, %6, 0x2c0\n\t"
-                 "s_load_dword %4, %6, 0x300\n\ts_load_dword %5, %6, 0x340\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(p));
+               : "=&s"(u0), "=&s"(u1), "=&s"(u2), "=&s"(u3), "=&s"(u4), "=&s"(u5), "=&s"(u6), "=&s"(u7)
+               : "s"(p), "n"(DQL_LINE(8)), "n"(DQL_LINE(9)), "n"(DQL_LINE(10)), "n"(DQL_LINE(11)), "n"(DQL_LINE(12)), "n"(DQL_LINE(13)), "n"(DQL_LINE(14)), "n"(DQL_LINE(15)),
+                 "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));
+#undef DQL_LINE
 }
 // TICK: layout of the 500 Hz loop (dql_device.hpp, agent_period: TICK_PLAIN / TICK_LONE / TICK_PACKED / TICK_LIT; launch_step_b
 // chooses).  Resident waves per SIMD by workgroup size:
@@ -1430,7 +1429,7 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");
   if (!strcmp(name, "periods_per_launch")) {
-    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..8");
+    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..16");
     x->periods_per_launch = value;
     return DQL_OK;
   }

@@ -140,8 +140,8 @@ class Trainer:
         self._periods_per_launch = int(periods_per_launch)
         self._eps_tail = None if eps_tail is None else float(eps_tail)
         self._eps_tail_after = float(eps_tail_after)
-        if not 1 <= self._periods_per_launch <= 8 or self._chunk_steps % self._periods_per_launch:
-            raise ValueError("periods_per_launch must be in 1..8 and divide chunk_steps")
+        if not 1 <= self._periods_per_launch <= 16 or self._chunk_steps % self._periods_per_launch:
+            raise ValueError("periods_per_launch must be in 1..16 and divide chunk_steps")
         # device None: GPU LOCAL_RANK of a multi-rank launch (one process per GPU), GPU 0 of a single process; an explicit device wins
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
         self._device_arg = device

@@ -415,7 +415,15 @@ static void bwc_init(bwc_t* b, double c) {
 }
 /* pkg/filters.py:98-109; history x1,x2 = previous two inputs, y1..y3 = previous three outputs (the deque keeps 3) */
 static inline REAL butterworth(const bwc_t* b, REAL x0, REAL* x1, REAL* x2, REAL* y1, REAL* y2, REAL* y3) {
+  /* FLOAT32 TICK, ROUND 3 (csrc/dql_device.hpp, Fast32): the float64 build spells the reference's expressions out operation by
+   * operation — it is what the golden vectors pin.  The float32 build takes the same formulas in their shortest
+   * correctly-rounded-per-operation form (products folded into the additions that consume them, dt/m, dt g, dt/I multiplied out on
+   * the host, two Newton steps from a second-order start in yaw_cs), exactly as the float32 kernel does: ORACLE_F32 below. */
+#if ORACLE_F32
+  REAL acc = FMA(-b->k1, *y3, FMA(R_(2.0), *x1, *x2) + x0);
+#else
   REAL acc = *x2 + R_(2.0) * *x1 + x0 - b->k1 * *y3;
+#endif
   if (b->k2 != R_(0.0)) acc = acc - (b->k2 * *y2); /* -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106) */
   const REAL value = b->inv_denom * acc;
   *x2 = *x1; *x1 = x0;
@@ -426,9 +434,17 @@ typedef struct { REAL kp, ki, kd, lo, hi, windup, setpoint; } pidc_t;
 /* pkg/pid.py:62-104 with delta_t > 0 */
 static inline REAL pid_output(const pidc_t* c, const bwc_t* b, pid_t_* s, REAL delta_t) {
   const REAL e0 = c->setpoint - s->state;
+#if ORACLE_F32
+  s->integ = clip3(FMA(e0, delta_t, s->integ), -c->windup, c->windup);
+#else
   s->integ = clip3(s->integ + e0 * delta_t, -c->windup, c->windup);
+#endif
   const REAL fe = butterworth(b, e0, &s->x1, &s->x2, &s->y1, &s->y2, &s->y3);
+#if ORACLE_F32
+  REAL eff = FMA(c->kp, fe, c->ki * s->integ);
+#else
   REAL eff = c->kp * fe + c->ki * s->integ;
+#endif
   if (c->kd != R_(0.0)) {
     const REAL draw = (e0 - s->e1) / delta_t;
     const REAL fd = butterworth(b, draw, &s->dx1, &s->dx2, &s->dy1, &s->dy2, &s->dy3);
@@ -451,6 +467,7 @@ static inline REAL kalman1d(REAL* x, REAL* P, REAL Q, REAL Rm, REAL z) {
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   REAL dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
+  REAL dtm, dtg, dtI[3]; /* dt / m, dt g, dt / I (float32 tick) */
   REAL kR[3], kW[3], ia, ib, ic; /* inverse allocation coefficients */
   pidc_t pvz, pyaw; bwc_t bw;
   REAL mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma, p_max;
@@ -462,6 +479,8 @@ typedef struct {
 
 static void simc_init(simc_t* s, const dql_config* c) {
   s->dt = (REAL)c->dt; s->g = (REAL)c->gravity; s->inv_m = (REAL)(1.0 / c->mass);
+  s->dtm = (REAL)(c->dt / c->mass); s->dtg = (REAL)(c->dt * c->gravity);
+  for (int i = 0; i < 3; ++i) s->dtI[i] = (REAL)(c->dt / c->inertia[i]);
   for (int i = 0; i < 3; ++i) { s->I[i] = (REAL)c->inertia[i]; s->inv_I[i] = (REAL)(1.0 / c->inertia[i]); s->kR[i] = (REAL)c->k_R[i]; s->kW[i] = (REAL)c->k_W[i]; }
   s->l = (REAL)c->arm_length; s->h = (REAL)c->rotor_z; s->kf = (REAL)c->k_f; s->km = (REAL)c->k_m;
   s->lkf = (REAL)(c->arm_length * c->k_f); s->kmkf = (REAL)(c->k_m * c->k_f);
@@ -500,8 +519,14 @@ static inline void quat_to_R(const REAL* q, REAL R[9]) {
 static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) {
   const REAL n2 = FMA(R[0], R[0], R[3] * R[3]);
   const REAL h = R_(-0.5) * n2;
+#if ORACLE_F32 /* second-order start 1 + d/2 + 3 d^2/8, d = 1 - n2, then two Newton steps */
+  const REAL d = R_(1.0) - n2;
+  REAL r = FMA(FMA(R_(0.375), d, R_(0.5)), d, R_(1.0));
+  for (int k = 0; k < 2; ++k) r = r * FMA(h * r, r, R_(1.5));
+#else
   REAL r = FMA(R_(-0.5), n2, R_(1.5));
-  for (int k = 0; k < (ORACLE_F32 ? 4 : 5); ++k) r = r * FMA(h * r, r, R_(1.5));
+  for (int k = 0; k < 5; ++k) r = r * FMA(h * r, r, R_(1.5));
+#endif
   *c = R[0] * r; *s = R[3] * r;
 }
 
@@ -514,12 +539,22 @@ static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], c
   const REAL E01 = E_(0, 1), E10 = E_(1, 0), E02 = E_(0, 2), E20 = E_(2, 0), E12 = E_(1, 2), E21 = E_(2, 1), E22 = E_(2, 2);
 #undef E_
   const REAL eR0 = R_(0.5) * (E21 - E12), eR1 = R_(0.5) * (E02 - E20), eR2 = R_(0.5) * (E10 - E01);
+#if ORACLE_F32
+  const REAL eW0 = FMA(-r_cmd, E02, w[0]), eW1 = FMA(-r_cmd, E12, w[1]), eW2 = FMA(-r_cmd, E22, w[2]);
+  M[0] = FMA(-eW0, s->kW[0], -(eR0 * s->kR[0]));
+  M[1] = FMA(-eW1, s->kW[1], -(eR1 * s->kR[1]));
+  M[2] = FMA(-eW2, s->kW[2], -(eR2 * s->kR[2]));
+  const REAL a = thrust * s->ia;
+  const REAL w2[4] = {FMA(M[2], s->ic, FMA(-M[1], s->ib, a)), FMA(-M[2], s->ic, FMA(M[0], s->ib, a)), FMA(M[2], s->ic, FMA(M[1], s->ib, a)),
+                      FMA(-M[2], s->ic, FMA(-M[0], s->ib, a))};
+#else
   const REAL eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
   M[0] = -(eR0 * s->kR[0]) - eW0 * s->kW[0];
   M[1] = -(eR1 * s->kR[1]) - eW1 * s->kW[1];
   M[2] = -(eR2 * s->kR[2]) - eW2 * s->kW[2];
   const REAL a = thrust * s->ia, bx = M[0] * s->ib, by = M[1] * s->ib, cz = M[2] * s->ic;
   const REAL w2[4] = {a - by + cz, a + bx - cz, a + by + cz, a - bx - cz};
+#endif
   for (int i = 0; i < 4; ++i) cmd[i] = SQRT(w2[i] > R_(0.0) ? w2[i] : R_(0.0));
 }
 
@@ -549,17 +584,25 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
     e->om[i] = FMA(a, e->om[i], (R_(1.0) - a) * ref);
   }
   /* translation */
-  const REAL ax = FMA(R[0], Fbx, FMA(R[1], Fby, R[2] * Fbz)) * s->inv_m;
-  const REAL ay = FMA(R[3], Fbx, FMA(R[4], Fby, R[5] * Fbz)) * s->inv_m;
-  const REAL az = FMA(R[6], Fbx, FMA(R[7], Fby, R[8] * Fbz)) * s->inv_m - s->g;
+  const REAL Fwx = FMA(R[0], Fbx, FMA(R[1], Fby, R[2] * Fbz)), Fwy = FMA(R[3], Fbx, FMA(R[4], Fby, R[5] * Fbz)), Fwz = FMA(R[6], Fbx, FMA(R[7], Fby, R[8] * Fbz));
+#if ORACLE_F32
+  e->v[0] = FMA(s->dtm, Fwx, e->v[0]); e->v[1] = FMA(s->dtm, Fwy, e->v[1]); e->v[2] = FMA(s->dtm, Fwz, e->v[2]) - s->dtg;
+#else
+  const REAL ax = Fwx * s->inv_m, ay = Fwy * s->inv_m, az = Fwz * s->inv_m - s->g;
   e->v[0] = FMA(s->dt, ax, e->v[0]); e->v[1] = FMA(s->dt, ay, e->v[1]); e->v[2] = FMA(s->dt, az, e->v[2]);
+#endif
   e->p[0] = FMA(s->dt, e->v[0], e->p[0]); e->p[1] = FMA(s->dt, e->v[1], e->p[1]); e->p[2] = FMA(s->dt, e->v[2], e->p[2]);
   /* rotation: I w' = tau - w x I w */
   const REAL Iw0 = s->I[0] * w[0], Iw1 = s->I[1] * w[1], Iw2 = s->I[2] * w[2];
   const REAL g0 = FMA(w[1], Iw2, -(w[2] * Iw1)), g1 = FMA(w[2], Iw0, -(w[0] * Iw2)), g2 = FMA(w[0], Iw1, -(w[1] * Iw0));
+#if ORACLE_F32
+  { const REAL w0 = w[0], w1 = w[1], w2_ = w[2];
+    e->w[0] = FMA(s->dtI[0], tx - g0, w0); e->w[1] = FMA(s->dtI[1], ty - g1, w1); e->w[2] = FMA(s->dtI[2], tz - g2, w2_); }
+#else
   e->w[0] = FMA(s->dt, (tx - g0) * s->inv_I[0], w[0]);
   e->w[1] = FMA(s->dt, (ty - g1) * s->inv_I[1], w[1]);
   e->w[2] = FMA(s->dt, (tz - g2) * s->inv_I[2], w[2]);
+#endif
   const REAL qw = e->q[0], qx = e->q[1], qy = e->q[2], qz = e->q[3], hdt = R_(0.5) * s->dt;
   const REAL dw = -FMA(qx, w[0], FMA(qy, w[1], qz * w[2]));
   const REAL dxq = FMA(qw, w[0], FMA(qy, w[2], -(qz * w[1])));

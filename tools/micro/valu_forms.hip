@@ -32,6 +32,10 @@ __device__ __forceinline__ unsigned long long real_clock() { unsigned long long 
   static const int NAME##_vpg = VPG;
 
 K(k_fma, "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n", 4)
+// dependent-issue latency: ONE chain (every instruction consumes its predecessor's result), two chains, and the mixed forms of the tick
+K(k_fma_dep1, "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n", 4)
+K(k_fma_dep2, "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n", 4)
+K(k_mul_dep1, "v_mul_f32 %0, %0, %4\n v_add_f32 %0, %0, %5\n v_mul_f32 %0, %0, %4\n v_add_f32 %0, %0, %5\n", 4)
 K(k_cnd_vcc, "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n", 4)
 K(k_cnd_sgpr, "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n", 4)
 K(k_cmp_vcc, "v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %4\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %4\n", 4)
@@ -87,7 +91,8 @@ int main() {
   float* d; (void)hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
   Stamp* st; (void)hipMalloc(&st, 256 * 8 * 4 * sizeof(Stamp));
   for (int w : {1, 2, 4}) {
-    RUN(k_fma, "v_fma_f32"); RUN(k_cnd_vcc, "v_cndmask_b32 vcc"); RUN(k_cnd_sgpr, "v_cndmask_b32 s[pair]"); RUN(k_cmp_vcc, "v_cmp_lt_f32 -> vcc");
+    RUN(k_fma, "v_fma_f32"); RUN(k_fma_dep1, "v_fma_f32, ONE dependent chain"); RUN(k_fma_dep2, "v_fma_f32, two chains"); RUN(k_mul_dep1, "v_mul / v_add alternating, one dependent chain");
+    RUN(k_cnd_vcc, "v_cndmask_b32 vcc"); RUN(k_cnd_sgpr, "v_cndmask_b32 s[pair]"); RUN(k_cmp_vcc, "v_cmp_lt_f32 -> vcc");
     RUN(k_cmp_sgpr, "v_cmp_lt_f32 -> s[pair]"); RUN(k_cmp_cnd, "v_cmp + v_cndmask back to back (per instr)"); RUN(k_cmp_cnd_far, "3 v_cmp, 3 v_cndmask, 2 v_fma (per instr)");
     RUN(k_max, "v_max_f32"); RUN(k_med3, "v_med3_f32"); RUN(k_and, "v_and_b32"); RUN(k_bfi, "v_bfi_b32"); RUN(k_mov, "v_mov_b32"); RUN(k_abs_mod, "v_add_f32 |src| (VOP3)");
     RUN(k_fma_salu1, "v_fma_f32 + 1 SALU each (per VALU)"); RUN(k_fma_salu4, "v_fma_f32 + 1 SALU per 4 (per VALU)"); RUN(k_fma_nop, "v_fma_f32 + s_nop per 4 (per VALU)");
