@@ -114,14 +114,16 @@ def cpu_baseline(envs: int, steps: int, dtype: int, cfg_kw: dict):
 # Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
 # (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
 # B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl,
-# r3_curriculum_32768_sweep1_variants.jsonl); 4 judged envs: the deque sees the episodes of 4 envs; 8 agent periods per launch and table
-# exchange every 8; eps_tail: level 0 follows the reference's exploration schedule, keeps its 0.01 floor for the first 192 episodes per
+# r3_curriculum_32768_sweep1_variants.jsonl); 2 judged envs: the deque sees the episodes of 2 envs; 16 agent periods per launch and table
+# exchange every 16; eps_tail: level 0 follows the reference's exploration schedule, keeps its 0.01 floor for the first 192 episodes per
 # env and then stops exploring — tables that LEARN from the floor's exploratory transitions fly 41 % of level 0's episodes out of the fly
 # zone, the same tables learning on without them 0.6 % (profiles/r3_level0_eps_tail.jsonl); stopping right away starves the later
 # levels of visited states (profiles/r3_curriculum_sweep2_eps_tail_immediate.jsonl)
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 4, "periods_per_launch": 8, "eps_tail": 0.0, "eps_tail_after": 192}
-CURRICULUM_SYNC = 8
-CURRICULUM_SEEDS = (42, 1, 2, 3, 4, 5)  # tabular RL is seed-noisy (touchdown 85-95 % between seeds): six full curricula, each reported
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 2, "periods_per_launch": 16, "eps_tail": 0.0, "eps_tail_after": 192}
+CURRICULUM_SYNC = 16
+# tabular RL is seed-noisy (per seed: goal-hold 0.87-0.96, touchdown 0.70-0.95, profiles/r3_curriculum_p8_p16_judge_sweep.jsonl): twelve
+# full curricula, each reported; 2 / 4 judged envs and 8 / 16 periods per launch are all within that noise of each other
+CURRICULUM_SEEDS = (42, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
 
 
 def curriculum_leg(args, comm, world, rank, dev_index, dtype):
@@ -297,11 +299,13 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (weak scaling); overrides the preset")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eps", type=float, default=1.0)
-    ap.add_argument("--sync-period", type=int, default=8,
-                    help="agent periods between table exchanges (N > 1).  Default 8 = periods per launch: the smallest window that costs no extra launch boundary; "
-                         "a rank then acts on tables that miss at most the other ranks' last 8 + 8 (one-launch fold delay) + 8 (window in flight) = 24 periods")
+    ap.add_argument("--sync-period", type=int, default=16,
+                    help="agent periods between table exchanges (N > 1).  Default 16 = periods per launch: the smallest window that costs no extra launch boundary; "
+                         "a rank then acts on tables that miss at most the other ranks' last 16 + 16 (one-launch fold delay) + 16 (window in flight) = 48 periods")
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--periods-per-launch", type=int, default=8, help="agent periods per kernel launch (engine option; 1 = one launch per period)")
+    ap.add_argument("--periods-per-launch", type=int, default=16,
+                    help="agent periods per kernel launch (engine option; 1 = one launch per period).  16: the launch boundary (state round trip through HBM, "
+                         "dispatch ramp and tail: 33 us at 131 072 envs) is paid once per 16 periods (32.2 -> 29.8 us per period against 8)")
     ap.add_argument("--two-axis", type=int, default=None, help="1 = joint x+y MDP (overrides the preset)")
     ap.add_argument("--randomize-platform", type=int, default=None, help="1 = per-env platform amplitude / speed (overrides the preset)")
     ap.add_argument("--noise", type=int, default=None, help="1 = observation noise 0.25 m / 0.1 m/s + Kalman R = 0.1^2 (overrides the preset)")
@@ -316,7 +320,7 @@ def main():
     ap.add_argument("--large-envs", type=int, default=1048576, help="secondary single-GPU block at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
     ap.add_argument("--curriculum-envs", type=int, default=32768, help="envs per GPU of the curriculum leg (BASELINE configs[3]: 262 144 / 8)")
-    ap.add_argument("--curriculum-seeds", type=int, default=6, help="how many of the six seeds to run")
+    ap.add_argument("--curriculum-seeds", type=int, default=12, help="how many of the twelve seeds to run")
     ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 384 per env")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -412,7 +416,7 @@ def main():
         # schedule, a yardstick), and at sync_period 2 (the regime in which the run does not depend on the number of ranks)
         w_none, d_none, _ = timed(args.steps + args.warmup + 1, args.steps, 0, final_exchange=False)
         others = {}
-        for sp in (2, 8, 32):
+        for sp in (2, 16, 32):
             if sp != args.sync_period:
                 w_sp, d_sp, _ = timed(sp, args.steps, 0)
                 others[f"sync_period_{sp}"] = {"value": d_sp / w_sp, "ms_per_step": w_sp * 1e3 / args.steps, "sync_ms_per_step": (w_sp - w_none) * 1e3 / args.steps}

@@ -254,7 +254,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   constexpr bool STAGED = BLOCK > 64;
   __shared__ unsigned long long sT[STAGED ? 2 * DQL_N_CELLS : 1];  // staged index = table * N_CELLS + cell (StepOut::cell)
   __shared__ unsigned int sM[STAGED ? 2 * DQL_N_CELLS : 1];
-  __shared__ unsigned long long sStat[4];
+  __shared__ unsigned long long sStat[4 + 7];  // decisions, episodes, reward sum, (spare), then the terminal histogram (codes 0 .. TERMINAL_TIMEOUT)
   warm_kernarg<(int)sizeof(StepArgs<T>)>();
   const int tid = threadIdx.x;
 #ifdef DQL_WAVE_CLOCK  // diagnostic build (tools/exp_wave_clock.py): wave start / end times in the episode log instead of the masks
@@ -277,7 +277,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   if (STAGED) {
     for (int t = 0; t < n_tab; ++t)
       for (int c = tid; c < ncell; c += BLOCK) { sT[t * DQL_N_CELLS + c] = 0ull; sM[t * DQL_N_CELLS + c] = 0u; }
-    if (tid < 4) sStat[tid] = 0ull;
+    if (tid < 4 + 7) sStat[tid] = 0ull;
     __syncthreads();
   }
   const long long i = (long long)blockIdx.x * BLOCK + tid;
@@ -301,9 +301,13 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     DQL_MARK_T(e, 2);
   }
   long long dec_w = 0, don_w = 0, rfx_w = 0;  // per-wave totals over the periods of this launch (wave-uniform after the reductions)
+  // terminal histogram of the wave over the launch: one ballot per CheckResult code and period instead of one global atomic per finished
+  // episode (thousands per period on a handful of addresses at large batches)
+  unsigned code_w[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   const TickConsts<TICK, T> tc(a.c);
   for (int p = 0; p < a.n_periods; ++p) {
     dec = 0; don = 0; rfx = 0; goal = false;
+    int done_code = -1;
     if (i < a.n) {
       const int ext = (a.mode == MODE_EXTERNAL) ? (int)a.actions[i] : 2;
       if (a.mode == MODE_EXTERNAL) {  // the caller's actions are checked here, not by a host loop (dql_step): ax | ay << 2, both in 0..2
@@ -321,7 +325,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
       }
       qx = o.next;  // the row of the state this period ended in = the next period's greedy row (the launch's tables act for all P)
       dec = o.decision; don = o.done; rfx = o.reward_fx;
-      if (o.done) { atomicAdd(&a.stats->by_code[e.code], 1ull); goal = e.code == DQL_TERMINAL_SUCCESS; }
+      if (o.done) { done_code = e.code; goal = e.code == DQL_TERMINAL_SUCCESS; }
     }
 #ifndef DQL_WAVE_CLOCK
     if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
@@ -333,6 +337,10 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
 #endif
     // wave64 shuffle reductions -> per-wave totals
     dec_w += __popcll(__ballot(dec != 0)); don_w += __popcll(__ballot(don != 0)); rfx_w += wave_sum(rfx);
+    if (__ballot(done_code >= 0)) {  // wave-uniform: most periods of most waves finish no episode
+#pragma unroll
+      for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) code_w[k] += (unsigned)__popcll(__ballot(done_code == k));
+    }
   }
   if (i < a.n) {
     store_env(e, a.sr, a.si, a.n, i, a.c);  // the atomics went out first: their round trip hides behind the state stores
@@ -347,6 +355,8 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
       if (dec) atomicAdd(&sStat[0], (unsigned long long)dec);
       if (don) atomicAdd(&sStat[1], (unsigned long long)don);
       if (rfx) atomicAdd(&sStat[2], (unsigned long long)rfx);
+#pragma unroll
+      for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) if (code_w[k]) atomicAdd(&sStat[4 + k], (unsigned long long)code_w[k]);
     }
     __syncthreads();
     for (int t = 0; t < n_tab; ++t)
@@ -354,12 +364,18 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
         const unsigned int m = sM[t * DQL_N_CELLS + c];
         if (m) { atomicAdd(&a.acc_cur[t * DQL_ACC_B + c], sT[t * DQL_N_CELLS + c]); atomicAdd(&a.acc_cur[t * DQL_ACC_B + DQL_N_CELLS + c], (unsigned long long)m); }
       }
-    if (tid == 0) { dec = (long long)sStat[0]; don = (long long)sStat[1]; rfx = (long long)sStat[2]; }
+    if (tid == 0) {
+      dec = (long long)sStat[0]; don = (long long)sStat[1]; rfx = (long long)sStat[2];
+#pragma unroll
+      for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) code_w[k] = (unsigned)sStat[4 + k];
+    }
   }
   if (tid == 0) {
     if (dec) atomicAdd(&a.stats->decisions, (unsigned long long)dec);
     if (don) atomicAdd(&a.stats->episodes, (unsigned long long)don);
     if (rfx) atomicAdd((unsigned long long*)&a.stats->reward_fx, (unsigned long long)rfx);
+#pragma unroll
+    for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) if (code_w[k]) atomicAdd(&a.stats->by_code[k], (unsigned long long)code_w[k]);
   }
 #ifdef DQL_WAVE_CLOCK
   if (DQL_WAVE_CLOCK == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); clk1 = wall_clock64(); }

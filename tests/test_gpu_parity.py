@@ -686,7 +686,7 @@ def test_periods_per_launch_bit_exact(mods, P, n, block, kw):
     eng = Engine(DqlConfig(dtype=dtype, **kw), n, seed=11); orc = Oracle(DqlConfig(dtype=dtype, **kw), n, seed=11)
     eng.set_option("periods_per_launch", P); orc.set_option("periods_per_launch", P)
     eng.set_option("block", block)
-    cap = 128
+    cap = max(128, 10 * P + 8)
     eng.episode_log_enable(cap); orc.episode_log_enable(cap)
     for steps, eps in ((P * 5 + 1, 1.0), (7, 0.3), (P * 9 + (P - 1), 0.0)):
         eng.train_steps(steps, eps); orc.train_steps(steps, eps)
