@@ -223,6 +223,21 @@ hb = strip(b.curriculum_training())
 assert ha == hb and len(ha) == 2, (ha, hb)
 for x, y in zip(a._engine.get_tables(), b._engine.get_tables()):
     assert np.array_equal(x, y)
+a._engine.close(); b._engine.close()
+# BASELINE configs[3] itself: the FULL 0 -> 4 curriculum at 32 768 envs per GPU with the unmodified 0.96 / 100 rule, the bench's trainer
+# settings (bench.CURRICULUM_KW: 16 periods per launch, table exchange every 16, 2 judged envs, exploration tail) — through the RCCL
+# reducer of one rank == through the local exchange: histories (promotions, episode counts, population success) and tables bit for bit
+import bench
+kw = dict(n_envs=32768, mode="paper", chunk_steps=64, sync_period=bench.CURRICULUM_SYNC, max_num_episodes=384 * 32768, checkpoint_every=10**9, seed=42, **bench.CURRICULUM_KW)
+a = T.Trainer(save_path=d + "/c", comm=comm, reducer_factory=comm.reducer, **kw)
+ha = strip(a.curriculum_training())
+b = T.Trainer(save_path=d + "/d", reducer_factory=LocalWindowReducer, **kw)
+hb = strip(b.curriculum_training())
+assert ha == hb and [h["level"] for h in ha] == [0, 1, 2, 3, 4], (ha, hb)
+assert ha[0]["promoted"] and ha[0]["success_rate"] > 0.95, ha[0]          # level 0 passes the reference's rule, and the POPULATION is there too
+assert sum(h["promoted"] for h in ha) >= 4, ha
+for x, y in zip(a._engine.get_tables(), b._engine.get_tables()):
+    assert np.array_equal(x, y)
 assert "torch" not in sys.modules
 comm.close()
 print("RCCL_OK")
@@ -233,7 +248,7 @@ def test_rccl_reducer_world_size_1():
     """The RCCL exchange of libdql_hip.so on a single rank, in its own process and WITHOUT PyTorch: unique id, communicator,
     ncclAllReduce(int64, sum) of the window on the engine's stream, fold; the host-buffer control-plane collectives; the
     Trainer on the RCCL communicator.  With one rank the sum is the identity, so results equal the windowed oracle and
-    the local-exchange Trainer."""
+    the local-exchange Trainer — the 2-level miniature and the full 5-level curriculum at BASELINE configs[3]'s 32 768 envs per GPU."""
     import subprocess
     import sys
     from pathlib import Path
