@@ -109,7 +109,7 @@ SYMBOLS = {
     "dql_agent_set_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dql_agent_get_tables": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dql_agent_predict_resident": (C.c_int, [_vp, _vp, _i64, _vp]),
-    "dql_agent_update_resident": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "dql_agent_update_resident": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp]),

@@ -543,6 +543,7 @@ __global__ void k_update_seq(double* qa, double* qb, double* count, const int* s
 // resident agent (dql_agent_*): arguments and results in pinned host memory, read and written by the kernel itself
 struct AgentUpdIn { int sa, ns; double alpha, reward; int coin, done; };
 struct AgentUpdOut { double q_new, count_new; };
+struct AgentUpdTail { int next_action; int pad; };  // predict(next state of the LAST transition) on the updated tables: the reference's loop asks for it next
 __global__ void k_update_resident(double* qa, double* qb, double* count, const AgentUpdIn* in, AgentUpdOut* out, long long n, double gamma, uint32_t quirks) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (long long i = 0; i < n; ++i) {
@@ -550,6 +551,8 @@ __global__ void k_update_resident(double* qa, double* qb, double* count, const A
     out[i].q_new = agent_update_one(qa, qb, count, u.sa, u.ns, u.alpha, gamma, u.reward, quirks, u.coin != 0, u.done != 0);
     out[i].count_new = count[u.sa];
   }
+  AgentUpdTail* tail = (AgentUpdTail*)(out + n);
+  tail->next_action = agent_predict((const double*)qa, (const double*)qb, in[n - 1].ns);
   __threadfence_system();
 }
 __global__ void k_predict_resident(const double* qa, const double* qb, const int* idx, long long n, uint8_t* out) {
@@ -1696,7 +1699,7 @@ int dql_agent_predict_resident(dql_agent* a, const int32_t* idx, int64_t n, uint
   return DQL_OK;
 }
 int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma, const double* reward, int64_t n,
-                              uint32_t quirks, const uint8_t* coin, const uint8_t* done, double* q_new, double* count_new) {
+                              uint32_t quirks, const uint8_t* coin, const uint8_t* done, double* q_new, double* count_new, uint8_t* next_action) {
   CHECK_AGENT(a);
   if (n < 0 || (n > 0 && (!sa || !ns || !alpha || !reward))) return fail(DQL_EINVAL, "null array");
   if (n == 0) return DQL_OK;
@@ -1705,7 +1708,7 @@ int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns
   for (int64_t i = 0; i < n; ++i) if (sa[i] < 0 || sa[i] >= DQL_N_CELLS || ns[i] < 0 || ns[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "index out of range");
   HIP_TRY(hipSetDevice(a->device));
   const size_t in_b = (size_t)n * sizeof(AgentUpdIn);
-  { int rc = agent_pin(a, in_b + (size_t)n * sizeof(AgentUpdOut)); if (rc) return rc; }
+  { int rc = agent_pin(a, in_b + (size_t)n * sizeof(AgentUpdOut) + sizeof(AgentUpdTail)); if (rc) return rc; }
   AgentUpdIn* in = (AgentUpdIn*)a->pin;
   for (int64_t i = 0; i < n; ++i) in[i] = AgentUpdIn{sa[i], ns[i], alpha[i], reward[i], coin ? (int)coin[i] : 0, done ? (int)done[i] : 0};
   hipLaunchKernelGGL(k_update_resident, dim3(1), dim3(64), 0, a->stream, a->qa, a->qb, a->count, (const AgentUpdIn*)a->pin_dev, (AgentUpdOut*)((char*)a->pin_dev + in_b), (long long)n, gamma, quirks);
@@ -1713,6 +1716,7 @@ int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns
   HIP_TRY(wait_stream(a->stream));
   const AgentUpdOut* o = (const AgentUpdOut*)((const char*)a->pin + in_b);
   for (int64_t i = 0; i < n; ++i) { if (q_new) q_new[i] = o[i].q_new; if (count_new) count_new[i] = o[i].count_new; }
+  if (next_action) *next_action = (uint8_t)((const AgentUpdTail*)(o + n))->next_action;
   return DQL_OK;
 }
 

@@ -45,6 +45,7 @@ class DoubleQLearningAgent:
         self._lib = None
         self._res = None      # dql_agent*: the tables resident on the device between calls (created on first use)
         self._shadow = None   # what the device holds, padded to 5 levels: (qa, qb, count)
+        self._next = None     # (packed state, greedy action) the last update's kernel computed for its next state, on the tables as they are now
 
     # ---- resident device tables (include/dql.h dql_agent_*) ----
     def _resident(self):
@@ -68,6 +69,7 @@ class DoubleQLearningAgent:
         if sh is None or not all(a.shape == (n,) + TABLE_SHAPE[1:] and np.array_equal(a, b.reshape(TABLE_SHAPE)[:n]) for a, b in zip(host, sh)):
             sh = self._shadow = self._padded()
             _lib.check(lib.dql_agent_set_tables(self._res, *[a.ctypes.data_as(C.c_void_p) for a in sh]))
+            self._next = None  # the host wrote the tables: what the last update predicted for its next state no longer holds
         return lib, self._res
 
     def close(self):
@@ -157,17 +159,18 @@ class DoubleQLearningAgent:
         io["sa"][0] = cell; io["ns"][0] = pack_state(ns); io["alpha"][0] = alpha; io["reward"][0] = reward
         sel_b = False
         if self.mode == "reference":
-            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_REFERENCE, None, None, p["q_new"], p["c_new"]))
+            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_REFERENCE, None, None, p["q_new"], p["c_new"], p["act"]))
         else:
             sel_b = not u < 0.5
             io["coin"][0] = 1 if sel_b else 0; io["done"][0] = 1 if done else 0
-            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_PAPER, p["coin"], p["done"], p["q_new"], p["c_new"]))
+            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_PAPER, p["coin"], p["done"], p["q_new"], p["c_new"], p["act"]))
         # the kernel reports the one cell it changed and its visit counter: patch the host arrays and the shadow of the device copy
         q_new, c_new = float(io["q_new"][0]), float(io["c_new"][0])
         (self.Q_table_b if sel_b else self.Q_table_a)[sa] = q_new
         self.state_action_counter[sa] = c_new
         self._shadow[1 if sel_b else 0][cell] = q_new
         self._shadow[2][cell] = c_new
+        self._next = (int(io["ns"][0]), int(io["act"][0]))
 
     # ---- pkg/double_q_learning.py:110-124 ----
     def guess(self, state: State, exploration_rate: float):
@@ -176,8 +179,11 @@ class DoubleQLearningAgent:
 
     def predict(self, state: State):
         s = self._check_state(state, 5)
-        lib, res = self._resident()
-        self._io["idx"][0] = pack_state(s)
+        lib, res = self._resident()   # (re-uploads and forgets self._next if the host arrays were written)
+        idx = pack_state(s)
+        if self._next is not None and self._next[0] == idx:
+            return self._next[1]        # the update kernel already answered this on the current tables
+        self._io["idx"][0] = idx
         _lib.check(lib.dql_agent_predict_resident(res, self._ptr["idx"], 1, self._ptr["act"]))
         return int(self._io["act"][0])
 

@@ -367,7 +367,8 @@ int dql_agent_get_tables(dql_agent* agent, double* qa_or_null, double* qb_or_nul
 int dql_agent_predict_resident(dql_agent* agent, const int32_t* idx, int64_t n, uint8_t* action_out);
 int dql_agent_update_resident(dql_agent* agent, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma, const double* reward,
                               int64_t n, uint32_t quirks, const uint8_t* coin_or_null, const uint8_t* done_or_null, double* q_new_out,
-                              double* count_new_out);
+                              double* count_new_out, uint8_t* next_action_out_or_null /* predict(ns[n-1]) on the updated tables: the
+                              reference's loop (pkg/trainer.py:191-212) asks for exactly that next, and gets it without a second round trip */);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:

@@ -4,7 +4,8 @@ curriculum training of the tabular Double-Q landing agent on one MI355X.
 
     python scripts/training.py [--envs 4096] [--mode reference|paper] [--out DIR] [--max-steps-per-level N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-        scripts/training.py --envs 262144 --sync-period 4        # BASELINE config 4: one rank per GPU, RCCL table exchange
+        scripts/training.py --envs 262144 --recipe bench         # BASELINE configs[3]: one rank per GPU, RCCL table exchange every 16 periods
+    python scripts/training.py --envs 32768 --recipe bench       # its per-GPU share on one GPU: the curriculum leg of bench.py (stage 4 after ~1.6 s)
 (torch.distributed.run is only the process launcher here; any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
 MASTER_PORT will do.  The ranks themselves never import PyTorch.)
 """
@@ -32,7 +33,12 @@ if __name__ == "__main__":
     ap.add_argument("--sync-period", type=int, default=None, help="agent periods between table exchanges (default: none on one GPU, 2 on several; given on one GPU it runs the same windowed schedule)")
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--t-max", type=int, default=20)
-    ap.add_argument("--judge-envs", type=int, default=4096)
+    ap.add_argument("--judge-envs", type=int, default=1, help="whose episodes feed the promotion deque (1 = the reference's own situation, Trainer default)")
+    ap.add_argument("--periods-per-launch", type=int, default=1, help="agent periods per kernel launch, 1..16 (must divide --chunk and --sync-period)")
+    ap.add_argument("--quirks", type=lambda v: int(v, 0), default=None, help="override of the mode's quirk set (include/dql.h DQL_Q_*), e.g. 0x60")
+    ap.add_argument("--eps-tail", type=float, default=None, help="exploration rate of level 0 once the reference's schedule has decayed (default: the reference's 0.01 floor)")
+    ap.add_argument("--eps-tail-after", type=float, default=0.0, help="... from this many episodes per env on")
+    ap.add_argument("--recipe", default=None, choices=["bench"], help="bench: the trainer settings of bench.py's curriculum leg (bench.CURRICULUM_KW, mode paper, sync 16, 384 episodes per env and level)")
     ap.add_argument("--window", type=int, default=100, help="successive_successful_episodes (reference: 100)")
     a = ap.parse_args()
     import os
@@ -42,10 +48,16 @@ if __name__ == "__main__":
     from dql_multirotor_landing_amd.config import F32, F64
     from dql_multirotor_landing_amd.trainer import Trainer
     # one rank per GPU: the Trainer picks RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* up by itself (comm.RcclComm.from_env, RCCL inside libdql_hip.so)
-    tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local,
+    extra = dict(periods_per_launch=a.periods_per_launch, quirks=a.quirks, eps_tail=a.eps_tail, eps_tail_after=a.eps_tail_after)
+    if a.recipe == "bench":
+        import bench
+        extra = dict(bench.CURRICULUM_KW)
+        a.mode, a.sync_period, a.judge_envs = "paper", bench.CURRICULUM_SYNC, extra.pop("judge_envs")
+        a.max_episodes = a.max_episodes or 384 * a.envs
+    tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local if world > 1 else None,
                  promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
                  successive_successful_episodes=a.window,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate)
+                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate, **extra)
     hist = tr.curriculum_training()
     if rank == 0:
         print(json.dumps({"history": hist, "save_path": str(tr._save_path), "world": world}, indent=1))
