@@ -759,7 +759,9 @@ template <typename T, int BLOCK, int TICK> static void launch_step_t(dql_ctx* x,
 //          63.3 us, 196 608: 57.0 vs 52.8)
 //   tick   packed float32 tick while a SIMD hosts at most one env wave (<= 65 536 envs: 18.7 vs 20.2 us at 4 096, 20.8 vs 22.3 at
 //          32 768; beside a second wave a packed instruction costs two issue slots and the layout LOSES: 45 vs 36 us at 131 072);
-//          literal constants with the 512-thread block when the vehicle is the reference's; the plain loop otherwise.
+//          literal constants beyond 65 536 envs when the vehicle is the reference's (round 2 took them with the 512-thread block only; with 16
+//          periods per launch and the round-3 fixes they also win at 256: 98 304 envs 26.2 us, 131 072 28.4 vs 30.6 plain, 262 144 / 512: 51.6
+//          vs 58.8); the plain loop otherwise.
 //          2 (VGPR constants + grouped loop, the small-batch layout of round 1) is kept as an option only.
 // float64 has one layout (no packed f64 pipe to use, no 64-bit literals): plain.
 template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps, int np) {
@@ -771,7 +773,7 @@ template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps
     else launch_step_t<T, 256, TICK_PLAIN>(x, mode, eps, np);
   } else {
     if (block == 0) block = (x->n <= 8192) ? 64 : (x->n <= 196608 || tick == 2 || tick == 3 ? 256 : 512);
-    if (tick == 0) tick = x->n <= 65536 ? 3 : (block == 512 && x->lit_ok ? 4 : 1);
+    if (tick == 0) tick = x->n <= 65536 ? 3 : (x->lit_ok ? 4 : 1);  // round 3: literals win from two waves per SIMD on (131 072 envs, P = 16: 28.4 vs 30.6 us)
     if (tick == 4 && !x->lit_ok) tick = 1;
     if (block == 128 || (block == 512 && tick != 4)) tick = 1;
     if (tick == 4) {

@@ -131,3 +131,81 @@ def test_place_golden(ops, golden_dir):
         np.testing.assert_array_equal(ops.place(DqlConfig(dtype=F64, init_uniform=mode), pl[:, 0], pl[:, 2]), pl[:, 3])
     with pytest.raises(ValueError):
         ops.place(DqlConfig(init_uniform=3), [0.0], [0.0])
+
+
+def test_resident_agent_equals_stateless_operators(ops):
+    """dql_agent_* (tables resident on the device, arguments and results through pinned memory) == dql_agent_predict / dql_agent_update
+    (tables shipped per call) == the oracle, over a random sequence in both update rules; the reported (new cell value, new counter, greedy
+    action of the next state) are what the tables then hold."""
+    import ctypes as C
+    from dql_multirotor_landing_amd import _lib
+    from dql_multirotor_landing_amd.config import Q_PAPER, Q_REFERENCE
+    from oracle import oracle as orc
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for quirks in (Q_REFERENCE, Q_PAPER):
+        qa, qb, cnt = rng.normal(size=2835), rng.normal(size=2835), rng.integers(0, 50, 2835).astype(np.float64)
+        h = C.c_void_p()
+        _lib.check(lib.dql_agent_create(0, C.byref(h)))
+        _lib.check(lib.dql_agent_set_tables(h, p(qa), p(qb), p(cnt)))
+        ra, rb, rc = qa.copy(), qb.copy(), cnt.copy()       # stateless replay
+        oa, ob, oc = qa.copy(), qb.copy(), cnt.copy()       # oracle replay
+        for _ in range(40):
+            n = int(rng.integers(1, 6))
+            sa = rng.integers(0, 2835, n).astype(np.int32); ns = rng.integers(0, 945, n).astype(np.int32)
+            alpha, reward = rng.uniform(0.02, 1.0, n), rng.normal(size=n) * 5
+            coin, done = rng.integers(0, 2, n).astype(np.uint8), rng.integers(0, 2, n).astype(np.uint8)
+            q_new, c_new, nxt = np.zeros(n), np.zeros(n), np.zeros(1, np.uint8)
+            _lib.check(lib.dql_agent_update_resident(h, p(sa), p(ns), p(alpha), 0.99, p(reward), n, quirks, p(coin), p(done), p(q_new), p(c_new), p(nxt)))
+            ops.agent_update(ra, rb, rc, sa, ns, alpha, 0.99, reward, quirks=quirks, coin=coin, done=done)
+            orc.agent_update(oa, ob, oc, sa, ns, alpha, 0.99, reward, quirks=quirks, coin=coin, done=done)
+            assert c_new[-1] == rc[sa[-1]] and q_new[-1] in (ra[sa[-1]], rb[sa[-1]])
+            assert nxt[0] == ops.agent_predict(ra, rb, ns[-1:])[0]
+            idx = rng.integers(0, 945, 33).astype(np.int32); act = np.zeros(33, np.uint8)
+            _lib.check(lib.dql_agent_predict_resident(h, p(idx), 33, p(act)))
+            np.testing.assert_array_equal(act, ops.agent_predict(ra, rb, idx))
+        ga, gb, gc = np.zeros(2835), np.zeros(2835), np.zeros(2835)
+        _lib.check(lib.dql_agent_get_tables(h, p(ga), p(gb), p(gc)))
+        for got, want, o in ((ga, ra, oa), (gb, rb, ob), (gc, rc, oc)):
+            np.testing.assert_array_equal(got, want); np.testing.assert_array_equal(got, o)
+        assert lib.dql_agent_predict_resident(h, p(np.array([945], np.int32)), 1, p(np.zeros(1, np.uint8))) == _lib.EINVAL
+        _lib.check(lib.dql_agent_destroy(h))
+
+
+def test_step_outputs_and_kernel_side_action_check():
+    """dql_step_outputs == what the field getters say (state, reward, done, code, step count, cumulative reward, reset flag) in one round
+    trip; an out-of-range action handed straight to the C ABI is flown as "hold" and reported ONCE by the next outputs / stats call —
+    the host no longer loops over the actions."""
+    import ctypes as C
+    from dql_multirotor_landing_amd import _lib
+    from dql_multirotor_landing_amd.engine import Engine
+    n = 300
+    eng = Engine(DqlConfig(dtype=F64, t_max=2.0), n, seed=4)
+    twin = Engine(DqlConfig(dtype=F64, t_max=2.0), n, seed=4)
+    rng = np.random.default_rng(1)
+    for k in range(70):
+        a = rng.integers(0, 3, n).astype(np.uint8)
+        eng.step(a); twin.step(a)
+        o = eng.step_outputs()
+        reals, ints = eng.get_fields()
+        nm, im = eng.field_names(), eng.field_names(True)
+        np.testing.assert_array_equal(o["idx_x"], ints[im.index("idx_x")])
+        np.testing.assert_array_equal(o["reward"], reals[nm.index("reward")])
+        np.testing.assert_array_equal(o["cumulative_reward"], reals[nm.index("cum_x")])
+        np.testing.assert_array_equal(o["done"], ints[im.index("flags")] & 1)
+        np.testing.assert_array_equal(o["was_reset"], (ints[im.index("flags")] >> 3) & 1)
+        np.testing.assert_array_equal(o["code"], ints[im.index("code")])
+        np.testing.assert_array_equal(o["step_count"], ints[im.index("step_count")])
+    assert o["done"].sum() + o["was_reset"].sum() > 0
+    bad = np.full(n, 2, dtype=np.uint8); bad[7] = 3; bad[9] = 1 << 2      # ax = 3; a y action in an x-axis config
+    assert eng.lib.dql_step(eng._h, bad.ctypes.data_as(C.c_void_p)) == 0  # accepted: nobody loops over n_envs on the host
+    with pytest.raises(ValueError, match="2 action"):
+        eng.step_outputs()
+    eng.step_outputs()                                                   # reported once
+    hold = np.full(n, 2, dtype=np.uint8); hold[9] = 0
+    twin.step(hold)                                                      # ax = 3 flew as "hold"; env 9's x action (0) was flown, its y action had nothing to act on
+    np.testing.assert_array_equal(eng.get_fields()[0], twin.get_fields()[0])
+    with pytest.raises(ValueError):
+        eng.step(np.full(n, 3, dtype=np.uint8))                          # the Python layer still refuses up front, as the reference's step() raises
+    eng.close(); twin.close()
