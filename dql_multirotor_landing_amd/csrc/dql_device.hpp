@@ -54,6 +54,22 @@ DQL_DEV float sqrt_(float x) {
   return y;
 }
 DQL_DEV double sqrt_(double a) { return __builtin_sqrt(a); }
+// Correctly rounded sqrt for x >= 2^-102 in 1 transcendental + 7 full-rate instructions (v_rsq_f32, one Goldschmidt step on (x y, y / 2), one
+// residual correction — the sequence LLVM lowers an IEEE sqrt to when denormals are flushed) instead of sqrt_'s v_sqrt_f32 + 8 mostly four-cycle
+// ones.  EXHAUSTIVELY verified on gfx950: every one of the 2.13e9 positive normal float32 inputs against (float)sqrt((double)x) — the only
+// 1.8 M misroundings all lie below 2^-103, where the residual goes subnormal (tools/micro/sqrt_exhaustive.hip,
+// profiles/r3_sqrt_rsq_goldschmidt_exhaustive.jsonl; dql_selftest_sqrt re-runs the check inside this library).  The tick's four rotor
+// commands per physics tick use it on max(w^2, 1e-30).
+constexpr float SQRT_POS_MIN = 1e-30f;  // > 2^-102 = 1.97e-31
+DQL_DEV float sqrt_pos(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  float g = x * y, h = 0.5f * y;
+  const float r = __builtin_fmaf(-h, g, 0.5f);
+  g = __builtin_fmaf(g, r, g);
+  h = __builtin_fmaf(h, r, h);
+  const float d = __builtin_fmaf(-g, g, x);
+  return __builtin_fmaf(d, h, g);
+}
 DQL_DEV float abs_(float a) { return __builtin_fabsf(a); }
 DQL_DEV double abs_(double a) { return __builtin_fabs(a); }
 DQL_DEV float rint_(float a) { return __builtin_rintf(a); }
@@ -499,7 +515,7 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
     const T a = thrust * s.ia;
     const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cmd[i] = sqrt_(w2[i] > T(0.0) ? w2[i] : T(0.0));
+    for (int i = 0; i < 4; ++i) cmd[i] = sqrt_pos(w2[i] > SQRT_POS_MIN ? w2[i] : SQRT_POS_MIN);  // a rotor commanded to stop is commanded to 1e-15 rad/s
   } else {
     const T eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
     const T M0 = -(eR0 * s.kR[0]) - eW0 * s.kW[0];
@@ -778,8 +794,8 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const f2 ibn = f2{-(float)c.ib, (float)c.ib};
   const f2 w2_02 = pfma(bc2(M2), bc2((float)c.ic), pfma(hi2(M01), ibn, bc2(a)));          // fma(M2, ic, fma(-+M1, ib, a))
   const f2 w2_13 = pfma(bc2(M2), bc2(-(float)c.ic), pfma(lo2(M01), swp2(ibn), bc2(a)));   // fma(-M2, ic, fma(+-M0, ib, a))
-  const f2 cmd02 = f2{sqrt_(w2_02.x > 0.0f ? w2_02.x : 0.0f), sqrt_(w2_02.y > 0.0f ? w2_02.y : 0.0f)};
-  const f2 cmd13 = f2{sqrt_(w2_13.x > 0.0f ? w2_13.x : 0.0f), sqrt_(w2_13.y > 0.0f ? w2_13.y : 0.0f)};
+  const f2 cmd02 = f2{sqrt_pos(w2_02.x > SQRT_POS_MIN ? w2_02.x : SQRT_POS_MIN), sqrt_pos(w2_02.y > SQRT_POS_MIN ? w2_02.y : SQRT_POS_MIN)};
+  const f2 cmd13 = f2{sqrt_pos(w2_13.x > SQRT_POS_MIN ? w2_13.x : SQRT_POS_MIN), sqrt_pos(w2_13.y > SQRT_POS_MIN ? w2_13.y : SQRT_POS_MIN)};
   // ---- rotor forces from the CURRENT rotor speeds + rigid body (gazebo_motor_model.cpp:434-500) ----
   const float l = c.l, h = c.h;
   const f2 q02 = s.om02 * s.om02, q13 = s.om13 * s.om13;

@@ -511,6 +511,16 @@ __global__ void k_plant_run(SimK<T> c, long long n_series, long long n_ticks, co
     o[17] = e.mp_x; o[18] = e.mp_y; o[19] = (e.flags & FL_CONTACT) ? 1.0 : 0.0;
   }
 }
+// exhaustive self-test of sqrt_pos (dql_selftest_sqrt): inputs with bit patterns lo .. hi against (float)sqrt((double)x)
+__global__ void k_selftest_sqrt(unsigned lo, unsigned hi, unsigned long long* bad) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long n = 0;
+  for (unsigned long long b = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
+    const float x = __uint_as_float((unsigned)b);
+    if (__float_as_uint(sqrt_pos(x)) != __float_as_uint((float)__builtin_sqrt((double)x))) ++n;
+  }
+  if (n) atomicAdd(bad, n);
+}
 template <typename T> __global__ void k_place(int init_mode, T p_max, const double* x0, const double* mp, long long n, double* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (double)place_axis(init_mode, (T)x0[i], (T)mp[i], p_max);
@@ -1598,6 +1608,21 @@ int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n
   else hipLaunchKernelGGL(k_plant_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(*cfg), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const double*)b.p, (double*)o.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, o.p, cells * 20 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded) {
+  if (!not_correctly_rounded) return fail(DQL_EINVAL, "null pointer");
+  if (lo_bits > hi_bits || hi_bits > 0x7f7fffffu) return fail(DQL_EINVAL, "bit patterns must satisfy lo <= hi <= 0x7f7fffff (largest finite float32)");
+  OP_PROLOGUE(device)
+  DevBuf b;
+  if (b.alloc(sizeof(unsigned long long))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  HIP_TRY(hipMemset(b.p, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_selftest_sqrt, dim3(256 * 32), dim3(256), 0, 0, (unsigned)lo_bits, (unsigned)hi_bits, (unsigned long long*)b.p);
+  HIP_TRY(hipGetLastError());
+  unsigned long long n = 0;
+  HIP_TRY(hipMemcpy(&n, b.p, sizeof(n), hipMemcpyDeviceToHost));
+  *not_correctly_rounded = (int64_t)n;
   return DQL_OK;
 }
 

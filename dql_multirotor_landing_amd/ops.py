@@ -72,6 +72,14 @@ def plant_run(cfg: DqlConfig, init, rotor_cmd, device: int = 0) -> np.ndarray:
     return out
 
 
+def selftest_sqrt(lo: float = 1e-30, hi: float = 3.4028234663852886e38, device: int = 0) -> int:
+    """number of float32 inputs in [lo, hi] for which the float32 tick's square root is not the correctly rounded one (must be 0)"""
+    lo_b = int(np.float32(lo).view(np.uint32)); hi_b = int(np.float32(hi).view(np.uint32))
+    n = C.c_int64(-1)
+    _lib.check(_lib.load().dql_selftest_sqrt(device, lo_b, hi_b, C.byref(n)))
+    return n.value
+
+
 def place(cfg: DqlConfig, x0, mp, device: int = 0) -> np.ndarray:
     """Drone start coordinate for (random offset, platform coordinate) pairs: the reset placement selected by cfg.init_uniform."""
     x0, mp = _f64(x0), _f64(mp)

@@ -350,6 +350,10 @@ int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t
  * quaternion(4), body rates(3), rotor speeds(4), platform x y, contact latch (0 / 1) AFTER each tick.  Exists so that tests can hold
  * the plant against closed forms (tests/test_plant_closed_forms.py); Gazebo itself cannot run here (parity vs Gazebo: unpinned). */
 int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* init, const double* rotor_cmd, double* out);
+/* Self-test of the float32 tick's square root (csrc/dql_device.hpp sqrt_pos: v_rsq_f32 + Goldschmidt step + residual correction): counts the
+ * inputs with bit patterns lo_bits .. hi_bits whose result is NOT the correctly rounded sqrt.  The CPU oracle computes sqrtf(); parity is
+ * bit for bit only while this count is 0 on the tick's domain [1e-30, FLT_MAX] — all 2.1e9 inputs take under a second. */
+int dql_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded);
 /* start coordinate of the drone along one axis for n (random offset x0, platform coordinate) pairs: the placement arithmetic of
  * TrainingLandingEnv.reset / SimulationLandingEnv.reset selected by cfg->init_uniform (see dql_config) */
 int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out);

@@ -555,7 +555,11 @@ static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], c
   const REAL a = thrust * s->ia, bx = M[0] * s->ib, by = M[1] * s->ib, cz = M[2] * s->ic;
   const REAL w2[4] = {a - by + cz, a + bx - cz, a + by + cz, a - bx - cz};
 #endif
+#if ORACLE_F32 /* the kernel's sqrt_pos is the correctly rounded sqrt for x >= 2^-102 (exhaustively verified, dql_device.hpp): a stopped rotor is commanded 1e-15 rad/s */
+  for (int i = 0; i < 4; ++i) cmd[i] = SQRT(w2[i] > 1e-30f ? w2[i] : 1e-30f);
+#else
   for (int i = 0; i < 4; ++i) cmd[i] = SQRT(w2[i] > R_(0.0) ? w2[i] : R_(0.0));
+#endif
 }
 
 /* gazebo_motor_model.cpp:434-500 (forces from the CURRENT rotor speeds) + one semi-implicit Euler step of the body */

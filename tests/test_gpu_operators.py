@@ -209,3 +209,12 @@ def test_step_outputs_and_kernel_side_action_check():
     with pytest.raises(ValueError):
         eng.step(np.full(n, 3, dtype=np.uint8))                          # the Python layer still refuses up front, as the reference's step() raises
     eng.close(); twin.close()
+
+
+def test_float32_tick_square_root_is_correctly_rounded_on_its_whole_domain(ops):
+    """The float32 tick takes the rotor commands' square roots as v_rsq_f32 + Goldschmidt step + residual correction (1 transcendental + 7
+    full-rate instructions) and the oracle as sqrtf(): bit-for-bit parity needs the former to be THE correctly rounded root.  Exhaustive:
+    every float32 from 1e-30 (the tick clamps there) to FLT_MAX — 2.1e9 inputs; and the reason for the clamp: below 2^-103 it is not."""
+    assert ops.selftest_sqrt(1e-30, 3.4028234663852886e38) == 0
+    assert ops.selftest_sqrt(2.0 ** -102, 1e-30) == 0
+    assert ops.selftest_sqrt(2.0 ** -126, 2.0 ** -104) > 0
