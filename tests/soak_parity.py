@@ -25,12 +25,12 @@ for k in range(n_cfg):
     if rng.random() < 0.3: kw.update(per_env_platform=1)
     if rng.random() < 0.3: kw.update(noise_pos_sd=0.25, noise_vel_sd=0.1)
     if rng.random() < 0.3: kw.update(init_uniform=1)
-    n = int(rng.choice([1, 63, 64, 65, 200, 512, 700]))
+    n = int(rng.choice([1, 63, 64, 65, 200, 512, 700, 3000]))
     seed = int(rng.integers(0, 2**31))
     windowed = rng.random() < 0.3
     block = int(rng.choice([0, 0, 64, 128, 256, 512])) if kw["dtype"] == F32 else int(rng.choice([0, 0, 64, 128, 256]))
     tick = int(rng.integers(0, 5)) if kw["dtype"] == F32 else int(rng.integers(0, 4))   # 4 = literal constants: float32 + reference vehicle (the default config)
-    ppl = int(rng.choice([1, 1, 2, 3, 4]))
+    ppl = int(rng.choice([1, 1, 2, 3, 4, 8, 13, 16]))
     eng = Engine(DqlConfig(**kw), n, seed=seed); orc = Oracle(DqlConfig(**kw), n, seed=seed, n_threads=8)
     eng.set_option("block", block); eng.set_option("tick", tick)
     eng.set_option("periods_per_launch", ppl); orc.set_option("periods_per_launch", ppl)
