@@ -537,8 +537,11 @@ def valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms
     out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "valu_instr_per_env_wave_per_period": ref["SQ_INSTS_VALU_per_env_wave_per_period"],
            "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
            "source": f"profiles/{src} [{key}] (instruction count, same kernel sources), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
-    # own mix per tick (tools/isa_sections.py x the table above): plain loop 1.39 ns; literal-constant loop (> 196 608 envs) 1.27 ns; packed lone wave 2.3 ns
-    mix = 2.3 if lone else (1.27 if envs > 196608 else 1.39)
+    # own mix per tick (tools/isa_sections.py x the table above): literal-constant loop (> 65 536 envs with the reference vehicle, which is what
+    # bench.py flies) 1.27 ns at round 2's instruction mix — round 3's tick has fewer four-cycle forms (sqrt_pos), so this floor is a little
+    # high and the fraction a little flattering; packed lone wave 2.3 ns.  profiles/r3_valu_forms_clock.jsonl gives the same costs in CYCLES
+    # with the in-kernel clock (1.86-1.97 GHz under a dense full-rate stream at >= 2 waves, 2.25-2.4 GHz otherwise)
+    mix = 2.3 if lone else 1.27
     prices = (("all_full_rate", 2.2 if lone else 1.15), ("own_mix", mix), ("guide_table", (4 if lone else 2) / 2.4))
     for tag, ns in prices:
         floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)

@@ -56,6 +56,10 @@ class Engine:
             raise ValueError("actions must be ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold)")
         _lib.check(self.lib.dql_step(self._h, _p(a)))
 
+    def step_raw(self, a):
+        """`step` without the argument checks: `a` is a contiguous uint8[n] the caller vouches for (the kernel checks the codes again)"""
+        _lib.check(self.lib.dql_step(self._h, a.ctypes.data_as(C.c_void_p)))
+
     def step_dev(self, dev_ptr: int):
         """one agent step with actions that already live in device memory (n uint8, e.g. written by the caller's own policy kernel)"""
         _lib.check(self.lib.dql_step_dev(self._h, C.c_void_p(int(dev_ptr))))
@@ -120,6 +124,14 @@ class Engine:
             so = self._so = (o, [_p(o[k]) for k in ("idx_x", "idx_y", "reward", "done", "code", "step_count", "cumulative_reward", "was_reset")])
         _lib.check(self.lib.dql_step_outputs(self._h, *so[1]))
         return {k: v.copy() for k, v in so[0].items()}
+
+    def step_outputs_view(self):
+        """the same without the copies: the engine's own buffers, overwritten by the next call"""
+        if self.__dict__.get("_so") is None:
+            self.step_outputs()
+            return self._so[0]
+        _lib.check(self.lib.dql_step_outputs(self._h, *self._so[1]))
+        return self._so[0]
 
     def get_fields(self):
         nr, ni = self.n_fields()

@@ -60,6 +60,17 @@ class _SingleEnv:
     def __init__(self, cfg: DqlConfig, seed: int, device: int):
         self._vec = VecLandingEnv(1, config=cfg, seed=seed, device=device)
         self._info: Dict[str, Any] = {}
+        self._act = np.zeros(1, dtype=np.uint8)  # the one action byte handed to dql_step, allocated once
+
+    def _step1(self, action: int):
+        """one env, one step: dql_step + dql_step_outputs on preallocated buffers (the per-step cost of this API is host overhead)"""
+        eng = self._vec.engine
+        self._act[0] = action
+        eng.step_raw(self._act)
+        o = eng.step_outputs_view()
+        idx = int(o["idx_x"][0])
+        state = (idx // 189, (idx // 63) % 3, (idx // 21) % 3, (idx // 7) % 3, idx % 7)
+        return state, float(o["reward"][0]), o
 
     def close(self):
         self._vec.close()
@@ -95,10 +106,10 @@ class TrainingLandingEnv(_SingleEnv):
             raise ValueError("Cannot move in the y direction while training")
         if action_x not in (0, 1, 2):
             raise ValueError("action_x must be 0 (increase), 1 (decrease) or 2 (hold)")
-        s, r, d, info = self._vec.step(np.array([action_x], dtype=np.uint8))
-        out = self._info_for(info, reward=r[0])
-        out["Current reward"] = float(r[0])
-        return tuple(int(x) for x in s[0]), float(r[0]), "Termination condition" in out.keys(), out
+        state, r, o = self._step1(action_x)
+        out = self._info_for({"check_code": o["code"], "step_count": o["step_count"], "cumulative_reward": o["cumulative_reward"]}, reward=r)
+        out["Current reward"] = r
+        return state, r, "Termination condition" in out.keys(), out
 
 
 class SimulationLandingEnv(_SingleEnv):
