@@ -208,6 +208,11 @@ template <typename T> DQL_DEV void box_muller(uint32_t ra, uint32_t rb, T& n0, T
 // ---------------------------------------------------------------------------------------------
 // MdpK: used before / after the tick loop only; lives in device memory and is read with scalar loads AFTER the loop so
 // that its ~60 values never compete with the in-loop constants for SGPRs.
+// CONSTANT address space pointer to it: a load through a plain global pointer below the `asm volatile("" ::: "memory")` of period_end is no
+// longer provably unclobbered, and the compiler then fetches the struct with twelve VECTOR loads per lane and period (192 B per lane into 48
+// VGPRs).  Constant-address-space loads of a wave-uniform address are scalar loads
+// by definition (the buffer is written by hipMemcpy between launches only, never by a kernel).
+#define DQL_CONST_AS __attribute__((address_space(4)))
 template <typename T> struct MdpK {
   T p_max, v_max, a_max, theta_max, delta_theta, beta, sigma_a, min_alt;
   T w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
@@ -921,13 +926,19 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
   return c;
 }
 // End of an agent period: fresh Euler angles, discretise / check / reward (mdp.py:257-541), TD target (double_q_learning.py:136-145)
-template <typename T, typename TabPtr>
-DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T>* __restrict__ mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
+// SCALAR_MDP: fetch the MDP constants with scalar loads (constant address space) instead of twelve vector loads per lane and period.  An A/B
+// of the three choices inside ONE run (all / none / this) shows no time difference beyond 0.5 % at 4 096 ... 1 M envs — differences between
+// runs on different boxes are 2-3 % and had looked like an effect; what it does buy is registers: 14 VGPRs less in the multi-wave layouts, and
+// the 128-VGPR variant's scratch 164 -> 92 B per lane.  The lone-wave layouts (registers to spare) keep the plain pointer.
+template <bool SCALAR_MDP, typename T, typename TabPtr>
+DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
   StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
   const bool two = s.two_axis != 0;
   const int prev_idx = c.prev_idx, prev_idy = c.prev_idy;
   asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the tick loop
-  const MdpK<T> m = *mp;
+  MdpK<T> m;
+  if constexpr (SCALAR_MDP) __builtin_memcpy(&m, mp, sizeof(m));
+  else m = *(const MdpK<T>*)mp;
   T R[9];
   quat_to_R(e.q, R);
   const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
@@ -1029,7 +1040,7 @@ template <int TICK, typename T> struct TickConsts {
   }
 };
 template <int TICK, typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T>* __restrict__ mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
+DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
                              int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
   T B[9];
@@ -1156,7 +1167,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   }
   DQL_SECTION("epilogue");
   DQL_MARK_T(e, 4);
-  const StepOut o = period_end(s, mp, e, c, qa, qb, mode);
+#if defined(DQL_SCALAR_MDP_ALL)   // A/B builds (tools/ab_build.sh)
+  const StepOut o = period_end<true>(s, mp, e, c, qa, qb, mode);
+#elif defined(DQL_SCALAR_MDP_NONE)
+  const StepOut o = period_end<false>(s, mp, e, c, qa, qb, mode);
+#else
+  const StepOut o = period_end<!HOT>(s, mp, e, c, qa, qb, mode);
+#endif
   DQL_MARK_T(e, 5);
   return o;
 }

@@ -185,7 +185,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
 #define DQL_MAX_PERIODS 16  // agent periods one launch may run back to back per env (option "periods_per_launch")
 template <typename T> struct StepArgs {
   SimK<T> c;
-  const MdpK<T>* mdp;
+  const MdpK<T> DQL_CONST_AS* mdp;  // device buffer, read as constant memory (scalar loads)
   Quad<T>* sr; int4* si;
   const double* qa; const double* qb;  // ACTING tables of this launch: every accumulator up to launch j-2 folded in
   unsigned long long* acc_cur;         // [2][DQL_N_CELLS] of this launch: target sums (fixed point), visits
@@ -744,7 +744,7 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   const long long j = x->step_index, l = x->launch_index;
   StepArgs<T> a;
   a.c = make_simk<T>(x->cfg);
-  a.mdp = (const MdpK<T>*)x->mdpk;
+  a.mdp = (const MdpK<T> DQL_CONST_AS*)x->mdpk;
   a.sr = (Quad<T>*)x->sr; a.si = x->si;
   a.qa = x->tb[l & 1]; a.qb = x->tbb[l & 1]; a.acc_cur = (unsigned long long*)x->acc[l & 1];
   a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(l + 1) & 1]; a.qb_pub = x->tbb[(l + 1) & 1];
