@@ -35,6 +35,17 @@
 #define DQL_MARK_T(e, k) do { } while (0)
 #endif
 
+// -DDQL_PHASE_CLOCK: diagnostic build (tools/exp_phase_clock.py): shader cycles (s_memtime) each wave spends per phase of a launch, summed over
+// the launch's periods and written to the episode log buffer instead of the masks.  Phases: 0 state load, 1 period begin (Philox, action or
+// reset placement, set-point matrix), 2 physics ticks, 3 manager ticks, 4 period end (rotation, Euler pitch, discretise, check, reward, TD
+// target), 5 accumulation (LDS / global atomics, ballots, wave sums), 6 state store + accumulator flush.  No waits are inserted: a memory
+// latency is charged to the phase in which the wave stalls on it.
+#ifdef DQL_PHASE_CLOCK
+#define DQL_PHASE(e, k) do { const unsigned long long _t = __builtin_readcyclecounter(); (e).ph[k] += _t - (e).t_last; (e).t_last = _t; } while (0)
+#else
+#define DQL_PHASE(e, k) do { } while (0)
+#endif
+
 namespace dql {
 
 // ---------------------------------------------------------------------------------------------
@@ -288,6 +299,9 @@ constexpr int NF_REAL = 64, NF_INT = 7;
 template <typename T> struct Env {
 #ifdef DQL_WAVE_CLOCK
   unsigned long long mark;
+#endif
+#ifdef DQL_PHASE_CLOCK
+  unsigned long long ph[7], t_last;
 #endif
   T p[3], v[3], q[4], w[3], om[4];
   T vz_i, vz_x1, vz_x2, vz_y1, vz_y2, vz_y3, vz_state;
@@ -1048,6 +1062,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   constexpr bool HOT = TICK == TICK_LONE || TICK == TICK_PACKED;
   const auto& h = tc.h;
   DQL_MARK_T(e, 3);
+  DQL_PHASE(e, 1);
   T R[9], cy, sy;
   uint32_t mgr_in_step = 0;
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
@@ -1057,9 +1072,11 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s.div) : 0u;
   auto manager_tick = [&]() {
     DQL_SECTION("manager");
+    DQL_PHASE(e, 2);
     manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
     manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
     ++mgr_in_step; ++mgr_index;
+    DQL_PHASE(e, 3);
   };
   auto control_and_plant = [&]() {
     DQL_SECTION("pid");
@@ -1090,11 +1107,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
         e.mp_x = opq(ts.mp_xy.x); e.mp_y = opq(ts.mp_xy.y); e.mp_u = opq(ts.mp_uv.x); e.mp_v = opq(ts.mp_uv.y);
         {
           DQL_SECTION("manager");
+          DQL_PHASE(e, 2);
           float Rm[9];  // scoped: a long-lived array would be demoted to LDS by the compiler
           rot_to_array(rp, Rm);
           manager_states(Rm, rp.cy, rp.sy, e.v[2], e.vz_state, e.yw_state);
           manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
           ++mgr_in_step; ++mgr_index;
+          DQL_PHASE(e, 3);
         }
         ts.pid_state = mk2(e.vz_state, e.yw_state); ts.mp_xy = mk2(e.mp_x, e.mp_y); ts.mp_uv = mk2(e.mp_u, e.mp_v);
       }
@@ -1167,6 +1186,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   }
   DQL_SECTION("epilogue");
   DQL_MARK_T(e, 4);
+  DQL_PHASE(e, 2);
 #if defined(DQL_SCALAR_MDP_ALL)   // A/B builds (tools/ab_build.sh)
   const StepOut o = period_end<true>(s, mp, e, c, qa, qb, mode);
 #elif defined(DQL_SCALAR_MDP_NONE)
@@ -1175,6 +1195,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   const StepOut o = period_end<!HOT>(s, mp, e, c, qa, qb, mode);
 #endif
   DQL_MARK_T(e, 5);
+  DQL_PHASE(e, 4);
   return o;
 }
 

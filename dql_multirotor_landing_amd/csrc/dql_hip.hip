@@ -255,6 +255,9 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   __shared__ unsigned long long sT[STAGED ? 2 * DQL_N_CELLS : 1];  // staged index = table * N_CELLS + cell (StepOut::cell)
   __shared__ unsigned int sM[STAGED ? 2 * DQL_N_CELLS : 1];
   __shared__ unsigned long long sStat[4 + 7];  // decisions, episodes, reward sum, (spare), then the terminal histogram (codes 0 .. TERMINAL_TIMEOUT)
+#ifdef DQL_PHASE_CLOCK
+  const unsigned long long clk_start = __builtin_readcyclecounter();
+#endif
   warm_kernarg<(int)sizeof(StepArgs<T>)>();
   const int tid = threadIdx.x;
 #ifdef DQL_WAVE_CLOCK  // diagnostic build (tools/exp_wave_clock.py): wave start / end times in the episode log instead of the masks
@@ -299,6 +302,11 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     qx = load_qrow(a.qa, a.qb, (unsigned)iv.x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? iv.x : 0);
     load_env(e, a.sr, iv, a.n, i, a.c);
     DQL_MARK_T(e, 2);
+#ifdef DQL_PHASE_CLOCK
+    for (int k = 0; k < 7; ++k) e.ph[k] = 0;
+    e.t_last = clk_start;
+    DQL_PHASE(e, 0);
+#endif
   }
   long long dec_w = 0, don_w = 0, rfx_w = 0;  // per-wave totals over the periods of this launch (wave-uniform after the reductions)
   // terminal histogram of the wave over the launch: one ballot per CheckResult code and period instead of one global atomic per finished
@@ -327,7 +335,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
       dec = o.decision; don = o.done; rfx = o.reward_fx;
       if (o.done) { done_code = e.code; goal = e.code == DQL_TERMINAL_SUCCESS; }
     }
-#ifndef DQL_WAVE_CLOCK
+#if !defined(DQL_WAVE_CLOCK) && !defined(DQL_PHASE_CLOCK)
     if (a.elog) {  // finished episodes of this period in env order: one ballot pair per wave (pkg/trainer.py:218-224 needs the order)
       const unsigned long long dm = __ballot(don != 0), sm = __ballot(goal);
       const long long w = i >> 6, nw = (a.n + 63) >> 6;
@@ -337,6 +345,9 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
 #endif
     // wave64 shuffle reductions -> per-wave totals
     dec_w += __popcll(__ballot(dec != 0)); don_w += __popcll(__ballot(don != 0)); rfx_w += wave_sum(rfx);
+#ifdef DQL_PHASE_CLOCK
+    if (i < a.n) DQL_PHASE(e, 5);
+#endif
     if (__ballot(done_code >= 0)) {  // wave-uniform: most periods of most waves finish no episode
 #pragma unroll
       for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) code_w[k] += (unsigned)__popcll(__ballot(done_code == k));
@@ -377,6 +388,13 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
 #pragma unroll
     for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) if (code_w[k]) atomicAdd(&a.stats->by_code[k], (unsigned long long)code_w[k]);
   }
+#ifdef DQL_PHASE_CLOCK
+  if (i < a.n) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    DQL_PHASE(e, 6);
+    if (a.elog && (tid & 63) == 0) { const long long w = i >> 6, nw = (a.n + 63) >> 6; for (int k = 0; k < 7; ++k) a.elog[(size_t)k * nw + w] = e.ph[k]; }
+  }
+#endif
 #ifdef DQL_WAVE_CLOCK
   if (DQL_WAVE_CLOCK == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); clk1 = wall_clock64(); }
   if (DQL_WAVE_CLOCK == 8) {  // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and the XCC id above it (tools/exp_placement.py)
