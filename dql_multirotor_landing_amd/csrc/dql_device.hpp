@@ -236,6 +236,7 @@ template <typename T> struct MdpK {
 template <typename T> struct SimK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   T dtm, dtg, dtI[3];  // dt / m, dt g, dt / I: the float32 tick integrates with them (one fma per component, see FAST32)
+  T oup, odn, inv_mgr_dt;  // 1 - rotor alpha (up / down), 1 / (dt manager_div): float32 tick
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -253,7 +254,7 @@ template <typename T> struct SimK {
 DQL_DEV float to_vgpr(float x) { float y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 template <typename T> struct HotK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, lkf, kmkf, aup, adn, omax, cd, crd;
-  T dtm, dtg, dtI[3];
+  T dtm, dtg, dtI[3], oup, odn;
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -264,7 +265,7 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   HotK<float> h;
 #define DQL_HOT(f) h.f = to_vgpr(s.f)
   DQL_HOT(dt); DQL_HOT(g); DQL_HOT(inv_m); DQL_HOT(I[0]); DQL_HOT(I[1]); DQL_HOT(I[2]); DQL_HOT(inv_I[0]); DQL_HOT(inv_I[1]); DQL_HOT(inv_I[2]);
-  DQL_HOT(dtm); DQL_HOT(dtg); DQL_HOT(dtI[0]); DQL_HOT(dtI[1]); DQL_HOT(dtI[2]);
+  DQL_HOT(dtm); DQL_HOT(dtg); DQL_HOT(dtI[0]); DQL_HOT(dtI[1]); DQL_HOT(dtI[2]); DQL_HOT(oup); DQL_HOT(odn);
   DQL_HOT(l); DQL_HOT(h); DQL_HOT(kf); DQL_HOT(lkf); DQL_HOT(kmkf); DQL_HOT(aup); DQL_HOT(adn); DQL_HOT(omax); DQL_HOT(cd); DQL_HOT(crd);
   DQL_HOT(kR[0]); DQL_HOT(kR[1]); DQL_HOT(kR[2]); DQL_HOT(kW[0]); DQL_HOT(kW[1]); DQL_HOT(kW[2]); DQL_HOT(ia); DQL_HOT(ib); DQL_HOT(ic);
   DQL_HOT(vz_kp); DQL_HOT(vz_ki); DQL_HOT(vz_lo); DQL_HOT(vz_hi); DQL_HOT(vz_wind); DQL_HOT(vz_sp);
@@ -516,15 +517,37 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
   const T r = yaw_rnorm(fma_(R[0], R[0], R[3] * R[3]));
   c = R[0] * r; s = R[3] * r;
 }
+// the same + what the float32 attitude law builds the yaw-free attitude from: rn = 1 / cos(tilt), ct = cos(tilt) = n2 rn
+template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s, T& ct, T& rn) {
+  const T n2 = fma_(R[0], R[0], R[3] * R[3]);
+  rn = yaw_rnorm(n2);
+  c = R[0] * rn; s = R[3] * rn; ct = n2 * rn;
+}
 // attitude_controller.py:107-156
+// float32 (Fast32): E = R_des^T R with R_des = Rz(yaw) B and R = Rz(yaw) A, A = Ry(pitch) Rx(roll) the yaw-free attitude, is B^T A — and A needs
+// no yaw at all: its last row is R's, A00 = cos(pitch) = sqrt(R00^2 + R10^2) = ct, A10 = 0, sin / cos(roll) = R21 / ct, R22 / ct = R7 rn, R8 rn,
+// sin(pitch) = -R20.  5 multiplications + 19 for the seven entries instead of 2 + 12 (R_des) + 21; cy, sy are only needed by the manager tick.
 template <typename T, typename K>
-DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T r_cmd, T thrust, T (&cmd)[4]) {
-  T D[9];
+DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T ct, T rn, T r_cmd, T thrust, T (&cmd)[4]) {
+  T E01, E10, E02, E20, E12, E21, E22;
+  if constexpr (Fast32<T>::on) {
+    const T sr = R[7] * rn, cr = R[8] * rn;             // sin, cos of the roll angle
+    const T A01 = -(R[6] * sr), A02 = -(R[6] * cr);     // sin(pitch) sin(roll), sin(pitch) cos(roll)
+    E01 = fma_(B[0], A01, fma_(B[3], cr, B[6] * R[7]));
+    E02 = fma_(B[0], A02, fma_(B[3], -sr, B[6] * R[8]));
+    E10 = fma_(B[1], ct, B[7] * R[6]);
+    E12 = fma_(B[1], A02, fma_(B[4], -sr, B[7] * R[8]));
+    E20 = fma_(B[2], ct, B[8] * R[6]);
+    E21 = fma_(B[2], A01, fma_(B[5], cr, B[8] * R[7]));
+    E22 = fma_(B[2], A02, fma_(B[5], -sr, B[8] * R[8]));
+  } else {
+    T D[9];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { D[j] = fma_(cy, B[j], -(sy * B[3 + j])); D[3 + j] = fma_(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
+    for (int j = 0; j < 3; ++j) { D[j] = fma_(cy, B[j], -(sy * B[3 + j])); D[3 + j] = fma_(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
 #define DQL_E(i, j) fma_(D[i], R[j], fma_(D[3 + i], R[3 + j], D[6 + i] * R[6 + j]))
-  const T E01 = DQL_E(0, 1), E10 = DQL_E(1, 0), E02 = DQL_E(0, 2), E20 = DQL_E(2, 0), E12 = DQL_E(1, 2), E21 = DQL_E(2, 1), E22 = DQL_E(2, 2);
+    E01 = DQL_E(0, 1); E10 = DQL_E(1, 0); E02 = DQL_E(0, 2); E20 = DQL_E(2, 0); E12 = DQL_E(1, 2); E21 = DQL_E(2, 1); E22 = DQL_E(2, 2);
 #undef DQL_E
+  }
   const T eR0 = T(0.5) * (E21 - E12), eR1 = T(0.5) * (E02 - E20), eR2 = T(0.5) * (E10 - E01);
   if constexpr (Fast32<T>::on) {
     const T eW0 = fma_(-r_cmd, E02, w[0]), eW1 = fma_(-r_cmd, E12, w[1]), eW2 = fma_(-r_cmd, E22, w[2]);
@@ -552,8 +575,14 @@ template <typename T, typename K> DQL_DEV void rotor_filter(const K& s, Env<T>& 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const T ref = clip3(cmd[i], T(0.0), T(s.omax));  // cmd = sqrt(..) >= +0: min(cmd, omax)
-    const T a = ref > e.om[i] ? s.aup : s.adn;
-    e.om[i] = fma_(a, e.om[i], (T(1.0) - a) * ref);
+    if constexpr (Fast32<T>::on) {  // om + (1 - a) (ref - om): the same filter, one instruction less
+      const T d = ref - e.om[i];
+      const T c = d > T(0.0) ? T(s.oup) : T(s.odn);
+      e.om[i] = fma_(c, d, e.om[i]);
+    } else {
+      const T a = ref > e.om[i] ? s.aup : s.adn;
+      e.om[i] = fma_(a, e.om[i], (T(1.0) - a) * ref);
+    }
   }
 }
 // forces from the CURRENT rotor speeds (gazebo_motor_model.cpp:434-500) + semi-implicit Euler of one rigid body
@@ -656,8 +685,13 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
     if (s.quirks & DQL_Q_FROZEN_ACC_REFERENCE) dt_ = (T)mgr_index * s.mgr_dt;
     else dt_ = s.mgr_dt;
     if (dt_ <= T(0.0)) dt_ = T(0.01);
-    ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_);
-    if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_);
+    if (Fast32<T>::on && !(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) {  // constant divisor: one multiplication (float32 tick)
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) * s.inv_mgr_dt);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) * s.inv_mgr_dt);
+    } else {
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_);
+    }
     if (!(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e.vf_x = rvx; if (s.two_axis) e.vf_y = rvy; }
   }
   e.obs_px = opx; e.obs_py = opy; e.obs_vx = ovx; e.obs_vy = ovy; e.obs_ax = ax_; e.obs_ay = ay_;
@@ -719,7 +753,7 @@ struct TickPk {
   f2 pid_i, pid_x1, pid_x2, pid_y1, pid_y2, pid_y3, pid_state;  // (v_z controller, yaw controller)
   f2 mp_xy, mp_uv;
 };
-struct RotPk { f2 R04, R13, R26, R57, R01, R34, R67; float R8, cy, sy; };  // rotation matrix: symmetric partners + row pairs
+struct RotPk { f2 R04, R13, R26, R57, R01, R34, R67; float R8, cy, sy, ct, rn; };  // rotation matrix: symmetric partners + row pairs; yaw frame
 
 DQL_DEV void pack_tick(const Env<float>& e, TickPk& s) {
   s.q_wx = mk2(e.q[0], e.q[1]); s.q_yz = mk2(e.q[2], e.q[3]);
@@ -758,8 +792,9 @@ DQL_DEV void rot_pk(const TickPk& s, RotPk& r) {
   r.R57 = bc2(2.0f) * pfma(lo2(wx_wy), f2{-1.0f, 1.0f}, hi2(xz_yz));    // 2 (yz - wx), 2 (yz + wx)
   r.R01 = f2{r.R04.x, r.R13.x}; r.R34 = f2{r.R13.y, r.R04.y}; r.R67 = f2{r.R26.y, r.R57.y};
   const float R0 = r.R04.x, R3 = r.R13.y;
-  const float rr = yaw_rnorm(fma_(R0, R0, R3 * R3));
-  r.cy = R0 * rr; r.sy = R3 * rr;
+  const float n2 = fma_(R0, R0, R3 * R3);
+  const float rr = yaw_rnorm(n2);
+  r.cy = R0 * rr; r.sy = R3 * rr; r.ct = n2 * rr; r.rn = rr;
 }
 DQL_DEV void rot_to_array(const RotPk& r, float (&R)[9]) {
   R[0] = r.R04.x; R[1] = r.R13.x; R[2] = r.R26.x; R[3] = r.R13.y; R[4] = r.R04.y; R[5] = r.R57.x; R[6] = r.R26.y; R[7] = r.R57.y; R[8] = r.R8;
@@ -791,18 +826,18 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   s.pid_x2 = s.pid_x1; s.pid_x1 = e0; s.pid_y3 = s.pid_y2; s.pid_y2 = s.pid_y1; s.pid_y1 = fe;
   const f2 eff = pfma(k.kp, fe, k.ki * s.pid_i);
   const float thrust = clip3(eff.x, k.lo.x, k.hi.x), r_cmd = clip3(eff.y, k.lo.y, k.hi.y);
-  // ---- attitude law (attitude_controller.py:107-156) ----
-  const f2 cy2 = bc2(r.cy), sy2 = bc2(r.sy);
-  const f2 D01 = pfma(cy2, B01, -(sy2 * B34));
-  const f2 D34 = pfma(sy2, B01, cy2 * B34);
-  const f2 m25 = f2{r.sy, r.cy} * bc2(B5);                                 // (sy B5, cy B5)
-  const f2 D25 = pfma(f2{r.cy, r.sy}, bc2(B2), f2{-m25.x, m25.y});         // D2 = fma(cy, B2, -(sy B5)), D5 = fma(sy, B2, cy B5)
-  const f2 D67 = B67; const float D8 = B8;
-  // E_ij = fma(D[i], R[j], fma(D[3+i], R[3+j], D[6+i] R[6+j]))
-  const f2 E02_12 = pfma(D01, lo2(r.R26), pfma(D34, lo2(r.R57), D67 * bc2(r.R8)));          // (E02, E12)
-  const f2 E20_21 = pfma(lo2(D25), r.R01, pfma(hi2(D25), r.R34, bc2(D8) * r.R67));           // (E20, E21)
-  const f2 E01_10 = pfma(D01, swp2(r.R01), pfma(D34, swp2(r.R34), D67 * swp2(r.R67)));       // (E01, E10)
-  const float E22 = fma_(D25.x, r.R26.x, fma_(D25.y, r.R57.x, D8 * r.R8));
+  // ---- attitude law (attitude_controller.py:107-156): E = B^T A on the yaw-free attitude A (see attitude()) ----
+  const float R6 = r.R26.y, R7 = r.R57.y;
+  const float sr = R7 * r.rn, cr = r.R8 * r.rn;
+  const f2 A012 = f2{-(R6 * sr), -(R6 * cr)};                                            // (A01, A02)
+  const f2 crsr = f2{cr, -sr};                                                            // (A11, A12)
+  const f2 R78 = f2{R7, r.R8};                                                            // (A21, A22)
+  const f2 E01_02 = pfma(lo2(B01), A012, pfma(lo2(B34), crsr, lo2(B67) * R78));           // (E01, E02)
+  const f2 E21_22 = pfma(bc2(B2), A012, pfma(bc2(B5), crsr, bc2(B8) * R78));              // (E21, E22)
+  const f2 E10_20 = pfma(f2{B01.y, B2}, bc2(r.ct), f2{B67.y, B8} * bc2(R6));              // (E10, E20)
+  const float E12 = fma_(B01.y, A012.y, fma_(B34.y, -sr, B67.y * r.R8));
+  const f2 E02_12 = f2{E01_02.y, E12}, E20_21 = f2{E10_20.y, E21_22.x}, E01_10 = f2{E01_02.x, E10_20.x};
+  const float E22 = E21_22.y;
   const f2 hh = bc2(0.5f) * (E02_12 - E20_21);                              // (eR1, -eR0)
   const float eR2 = 0.5f * (E01_10.y - E01_10.x);
   const f2 eW01 = pfma(-bc2(r_cmd), E02_12, s.w01);
@@ -858,10 +893,11 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   {
     const f2 ref02 = f2{clip3(cmd02.x, 0.0f, (float)c.omax), clip3(cmd02.y, 0.0f, (float)c.omax)};
     const f2 ref13 = f2{clip3(cmd13.x, 0.0f, (float)c.omax), clip3(cmd13.y, 0.0f, (float)c.omax)};
-    const f2 a02 = f2{ref02.x > s.om02.x ? c.aup : c.adn, ref02.y > s.om02.y ? c.aup : c.adn};
-    const f2 a13 = f2{ref13.x > s.om13.x ? c.aup : c.adn, ref13.y > s.om13.y ? c.aup : c.adn};
-    s.om02 = pfma(a02, s.om02, (bc2(1.0f) - a02) * ref02);
-    s.om13 = pfma(a13, s.om13, (bc2(1.0f) - a13) * ref13);
+    const f2 d02 = ref02 - s.om02, d13 = ref13 - s.om13;
+    const f2 c02 = f2{d02.x > 0.0f ? (float)c.oup : (float)c.odn, d02.y > 0.0f ? (float)c.oup : (float)c.odn};
+    const f2 c13 = f2{d13.x > 0.0f ? (float)c.oup : (float)c.odn, d13.y > 0.0f ? (float)c.oup : (float)c.odn};
+    s.om02 = pfma(c02, d02, s.om02);
+    s.om13 = pfma(c13, d13, s.om13);
   }
   // ---- platform extrapolation between manager ticks + bumper contact test ----
   s.mp_xy = pfma(s.mp_uv, bc2(c.dt), s.mp_xy);
@@ -1063,7 +1099,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   const auto& h = tc.h;
   DQL_MARK_T(e, 3);
   DQL_PHASE(e, 1);
-  T R[9], cy, sy;
+  T R[9], cy, sy, ct = T(1.0), rn = T(1.0);
   uint32_t mgr_in_step = 0;
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
@@ -1084,7 +1120,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, h.yw_lo, h.yw_hi, h.yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
     DQL_SECTION("attitude");
-    attitude(h, R, e.w, B, cy, sy, r_cmd, thrust, cmd);
+    attitude(h, R, e.w, B, cy, sy, ct, rn, r_cmd, thrust, cmd);
     DQL_SECTION("motor_body");
     plant_step(h, e, R);
     rotor_filter(h, e, cmd);
@@ -1149,7 +1185,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
 #pragma unroll DQL_TICK_UNROLL
     for (int i = 0; i < n_ticks; ++i) {
       DQL_SECTION("rot");
-      quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+      quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
       if (phase == 0) manager_tick();
       phase = (phase + 1 == s.div) ? 0 : phase + 1;
       control_and_plant();
@@ -1163,7 +1199,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     for (;;) {
       while (left > 0 && !(s.div == DQL_GROUP && phase == 0 && left >= DQL_GROUP)) {
         DQL_SECTION("rot");
-        quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+        quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
         if (phase == 0) manager_tick();
         phase = (phase + 1 == s.div) ? 0 : phase + 1;
         control_and_plant();
@@ -1172,12 +1208,12 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
       if (left == 0) break;
       do {
         DQL_SECTION("rot");
-        quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+        quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
         manager_tick();
         control_and_plant();
 #pragma unroll
         for (int k = 1; k < DQL_GROUP; ++k) {
-          quat_to_R(e.q, R); yaw_cs(R, cy, sy);
+          quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
           control_and_plant();
         }
         left -= DQL_GROUP;

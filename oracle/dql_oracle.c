@@ -468,6 +468,7 @@ static inline REAL kalman1d(REAL* x, REAL* P, REAL Q, REAL Rm, REAL z) {
 typedef struct {
   REAL dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   REAL dtm, dtg, dtI[3]; /* dt / m, dt g, dt / I (float32 tick) */
+  REAL oup, odn, inv_mgr_dt; /* 1 - rotor alpha, 1 / manager period (float32 tick) */
   REAL kR[3], kW[3], ia, ib, ic; /* inverse allocation coefficients */
   pidc_t pvz, pyaw; bwc_t bw;
   REAL mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma, p_max;
@@ -481,6 +482,7 @@ static void simc_init(simc_t* s, const dql_config* c) {
   s->dt = (REAL)c->dt; s->g = (REAL)c->gravity; s->inv_m = (REAL)(1.0 / c->mass);
   s->dtm = (REAL)(c->dt / c->mass); s->dtg = (REAL)(c->dt * c->gravity);
   for (int i = 0; i < 3; ++i) s->dtI[i] = (REAL)(c->dt / c->inertia[i]);
+  s->oup = (REAL)(1.0 - c->rotor_alpha_up); s->odn = (REAL)(1.0 - c->rotor_alpha_down); s->inv_mgr_dt = (REAL)(1.0 / (c->dt * c->manager_div));
   for (int i = 0; i < 3; ++i) { s->I[i] = (REAL)c->inertia[i]; s->inv_I[i] = (REAL)(1.0 / c->inertia[i]); s->kR[i] = (REAL)c->k_R[i]; s->kW[i] = (REAL)c->k_W[i]; }
   s->l = (REAL)c->arm_length; s->h = (REAL)c->rotor_z; s->kf = (REAL)c->k_f; s->km = (REAL)c->k_m;
   s->lkf = (REAL)(c->arm_length * c->k_f); s->kmkf = (REAL)(c->k_m * c->k_f);
@@ -516,7 +518,7 @@ static inline void quat_to_R(const REAL* q, REAL R[9]) {
 /* cos/sin of yaw = atan2(R10, R00) without the angle (pkg/attitude_controller.py:136-137) */
 /* n2 = cos^2(tilt) is close to 1 in flight: 1/sqrt(n2) by Newton's iteration from r0 = 1.5 - 0.5 n2 (multiplies and fmas
  * only; converged to rounding for tilt < ~55 deg, degrades gracefully, never NaN, for a tumbling vehicle) */
-static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) {
+static inline void yaw_cs4(const REAL R[9], REAL* c, REAL* s, REAL* ct, REAL* rn) {
   const REAL n2 = FMA(R[0], R[0], R[3] * R[3]);
   const REAL h = R_(-0.5) * n2;
 #if ORACLE_F32 /* second-order start 1 + d/2 + 3 d^2/8, d = 1 - n2, then two Newton steps */
@@ -527,17 +529,34 @@ static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) {
   REAL r = FMA(R_(-0.5), n2, R_(1.5));
   for (int k = 0; k < 5; ++k) r = r * FMA(h * r, r, R_(1.5));
 #endif
-  *c = R[0] * r; *s = R[3] * r;
+  *c = R[0] * r; *s = R[3] * r; *ct = n2 * r; *rn = r; /* ct = cos(tilt), rn = 1 / cos(tilt): the float32 attitude law's yaw-free attitude */
 }
+static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) { REAL ct, rn; yaw_cs4(R, c, s, &ct, &rn); }
 
 /* pkg/attitude_controller.py:107-156: (R, body rates, B = Rx(roll_sp) Ry(pitch_sp), yaw rate cmd, thrust) -> rotor speed commands */
-static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], const REAL B[9], REAL cy, REAL sy, REAL r_cmd, REAL thrust,
+static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], const REAL B[9], REAL cy, REAL sy, REAL ct, REAL rn, REAL r_cmd, REAL thrust,
                             REAL cmd[4], REAL M[3]) {
+#if ORACLE_F32
+  /* float32 tick: E = R_des^T R = B^T A on the yaw-free attitude A = Ry(pitch) Rx(roll): last row = R's, A00 = ct, A10 = 0,
+   * sin / cos(roll) = R7 rn, R8 rn, sin(pitch) = -R6 (csrc/dql_device.hpp attitude()) */
+  (void)cy; (void)sy;
+  const REAL sr = R[7] * rn, cr = R[8] * rn;
+  const REAL A01 = -(R[6] * sr), A02 = -(R[6] * cr);
+  const REAL E01 = FMA(B[0], A01, FMA(B[3], cr, B[6] * R[7]));
+  const REAL E02 = FMA(B[0], A02, FMA(B[3], -sr, B[6] * R[8]));
+  const REAL E10 = FMA(B[1], ct, B[7] * R[6]);
+  const REAL E12 = FMA(B[1], A02, FMA(B[4], -sr, B[7] * R[8]));
+  const REAL E20 = FMA(B[2], ct, B[8] * R[6]);
+  const REAL E21 = FMA(B[2], A01, FMA(B[5], cr, B[8] * R[7]));
+  const REAL E22 = FMA(B[2], A02, FMA(B[5], -sr, B[8] * R[8]));
+#else
+  (void)ct; (void)rn;
   REAL D[9]; /* R_des = Rz(yaw) B */
   for (int j = 0; j < 3; ++j) { D[j] = FMA(cy, B[j], -(sy * B[3 + j])); D[3 + j] = FMA(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
 #define E_(i, j) FMA(D[i], R[j], FMA(D[3 + i], R[3 + j], D[6 + i] * R[6 + j])) /* (R_des^T R)_ij */
   const REAL E01 = E_(0, 1), E10 = E_(1, 0), E02 = E_(0, 2), E20 = E_(2, 0), E12 = E_(1, 2), E21 = E_(2, 1), E22 = E_(2, 2);
 #undef E_
+#endif
   const REAL eR0 = R_(0.5) * (E21 - E12), eR1 = R_(0.5) * (E02 - E20), eR2 = R_(0.5) * (E10 - E01);
 #if ORACLE_F32
   const REAL eW0 = FMA(-r_cmd, E02, w[0]), eW1 = FMA(-r_cmd, E12, w[1]), eW2 = FMA(-r_cmd, E22, w[2]);
@@ -584,8 +603,14 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   /* rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364) */
   for (int i = 0; i < 4; ++i) {
     const REAL ref = clip3(cmd[i], R_(0.0), s->omax);  /* cmd = sqrt(..) >= +0: min(cmd, omax) */
+#if ORACLE_F32 /* om + (1 - a)(ref - om): the same filter, one operation less */
+    const REAL d = ref - e->om[i];
+    const REAL c = d > R_(0.0) ? s->oup : s->odn;
+    e->om[i] = FMA(c, d, e->om[i]);
+#else
     const REAL a = ref > e->om[i] ? s->aup : s->adn;
     e->om[i] = FMA(a, e->om[i], (R_(1.0) - a) * ref);
+#endif
   }
   /* translation */
   const REAL Fwx = FMA(R[0], Fbx, FMA(R[1], Fby, R[2] * Fbz)), Fwy = FMA(R[3], Fbx, FMA(R[4], Fby, R[5] * Fbz)), Fwz = FMA(R[6], Fbx, FMA(R[7], Fby, R[8] * Fbz));
@@ -672,8 +697,16 @@ static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL
     if (s->quirks & DQL_Q_FROZEN_ACC_REFERENCE) dt_ = (REAL)mgr_index * s->mgr_dt; /* time since the first sample; B19 */
     else dt_ = s->mgr_dt;
     if (dt_ <= R_(0.0)) dt_ = R_(0.01); /* pkg/filters.py:67-69 */
+#if ORACLE_F32
+    if (!(s->quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { /* constant divisor: one multiplication (float32 tick) */
+      ax_ = kalman1d(&e->kal_x[0], &e->kal_P[0], s->kal_q, s->kal_r, (rvx - e->vf[0]) * s->inv_mgr_dt);
+      if (s->two_axis) ay_ = kalman1d(&e->kal_x[1], &e->kal_P[1], s->kal_q, s->kal_r, (rvy - e->vf[1]) * s->inv_mgr_dt);
+    } else
+#endif
+    {
     ax_ = kalman1d(&e->kal_x[0], &e->kal_P[0], s->kal_q, s->kal_r, (rvx - e->vf[0]) / dt_);
     if (s->two_axis) ay_ = kalman1d(&e->kal_x[1], &e->kal_P[1], s->kal_q, s->kal_r, (rvy - e->vf[1]) / dt_); /* y estimator only flies in 2-axis configs */
+    }
     if (!(s->quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e->vf[0] = rvx; if (s->two_axis) e->vf[1] = rvy; }
   }
   e->obs[0] = opx; e->obs[1] = opy; e->obs[2] = ovx; e->obs[3] = ovy; e->obs[4] = ax_; e->obs[5] = ay_;
@@ -752,18 +785,18 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   B[0] = cp_; B[1] = R_(0.0); B[2] = sp_;
   B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_);
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
-  REAL R[9], cy, sy;
+  REAL R[9], cy, sy, ct, rn;
   uint32_t mgr_in_step = 0;
   const int phase0 = (int)(g0 % s->div), first_mgr = phase0 ? s->div - phase0 : 0;
   const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s->div) : 0u; /* the period's last manager tick */
   for (int i = 0; i < n_ticks; ++i) {
     const int64_t g = g0 + i;
-    quat_to_R(e->q, R); yaw_cs(R, &cy, &sy);
+    quat_to_R(e->q, R); yaw_cs4(R, &cy, &sy, &ct, &rn);
     if (g % s->div == 0) { manager_tick(s, e, R, cy, sy, g / s->div, k0, k1, step_lo, step_hi, env_id, mgr_in_step, g_eager_noise || mgr_in_step == last_mgr); ++mgr_in_step; }
     const REAL thrust = pid_output(&s->pvz, &s->bw, &e->vz, s->dt);
     const REAL r_cmd = pid_output(&s->pyaw, &s->bw, &e->yaw, s->dt);
     REAL cmd[4], M[3];
-    attitude(s, R, e->w, B, cy, sy, r_cmd, thrust, cmd, M);
+    attitude(s, R, e->w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, M);
     motor_and_body(s, e, R, cmd);
     e->mp_x = FMA(e->mp_u, s->dt, e->mp_x); e->mp_y = FMA(e->mp_v, s->dt, e->mp_y);
     if (e->p[2] - s->bottom <= s->mp_top && FABS(e->p[0] - e->mp_x) <= s->mp_hx && FABS(e->p[1] - e->mp_y) <= s->mp_hy) e->flags |= FL_CONTACT;
@@ -982,11 +1015,11 @@ EXPORT void ORC(attitude_run)(const dql_config* c, const double* quat_xyzw, cons
   for (int64_t i = 0; i < n; ++i) {
     REAL q[4] = {(REAL)quat_xyzw[i * 4 + 3], (REAL)quat_xyzw[i * 4 + 0], (REAL)quat_xyzw[i * 4 + 1], (REAL)quat_xyzw[i * 4 + 2]};
     REAL w[3] = {(REAL)omega[i * 3], (REAL)omega[i * 3 + 1], (REAL)omega[i * 3 + 2]};
-    REAL R[9], cy, sy, sp_, cp_, sr_, cr_, B[9], out[4], M[3];
-    quat_to_R(q, R); yaw_cs(R, &cy, &sy);
+    REAL R[9], cy, sy, ct, rn, sp_, cp_, sr_, cr_, B[9], out[4], M[3];
+    quat_to_R(q, R); yaw_cs4(R, &cy, &sy, &ct, &rn);
     det_sincos((REAL)cmd[i * 4 + 1], &sp_, &cp_); det_sincos((REAL)cmd[i * 4 + 0], &sr_, &cr_);
     B[0] = cp_; B[1] = R_(0.0); B[2] = sp_; B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_); B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
-    attitude(&s, R, w, B, cy, sy, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M);
+    attitude(&s, R, w, B, cy, sy, ct, rn, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M);
     for (int k = 0; k < 3; ++k) moment[i * 3 + k] = M[k];
     for (int k = 0; k < 4; ++k) rotor[i * 4 + k] = out[k];
   }
