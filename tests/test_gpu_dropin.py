@@ -281,3 +281,41 @@ def test_g13_dropin_env_classes_return_what_the_reference_env_returned(golden_di
                 if done:
                     break
         env.close()
+
+
+def test_trainer_resume_on_the_hip_engine_equals_uninterrupted_run(tmp_path):
+    """Trainer.save -> Trainer.load -> curriculum_training() on the REAL engine (8 periods per launch, windowed table schedule,
+    env state + period index + promotion bookkeeping from the tagged checkpoint files): history and tables equal the uninterrupted run."""
+    import json
+    import dql_multirotor_landing_amd.trainer as T
+    kw = dict(curriculum_steps=3, n_envs=2048, chunk_steps=16, checkpoint_every=3, max_num_episodes=6000, t_max=3, periods_per_launch=8, sync_period=8,
+              successive_successful_episodes=10, success_rate=0.25, mode="paper", judge_envs=48, eps_floor=0.3)
+    strip = lambda hist: [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
+    full = T.Trainer(save_path=tmp_path / "full" / "01-01-2026 10:00:00", **kw)
+    h_full = strip(full.curriculum_training())
+    assert len(h_full) == 3
+
+    class Stop(Exception):
+        pass
+
+    part = T.Trainer(save_path=tmp_path / "part" / "01-01-2026 10:00:00", **kw)
+    n_saves = {"n": 0}
+    real_save = part.save
+    def save_then_stop():
+        real_save()
+        if part._progress is not None and part._progress["level"] == 1:
+            n_saves["n"] += 1
+            if n_saves["n"] == 1:
+                raise Stop()
+    part.save = save_then_stop
+    with pytest.raises(Stop):
+        part.curriculum_training()
+    part._engine.close()
+    st = json.loads((tmp_path / "part" / "01-01-2026 10:00:00" / "trainer.json").read_text())
+    assert st["progress"]["level"] == 1 and st["progress"]["tag"]["world"] == 1
+    back = T.Trainer.load(tmp_path / "part")
+    h_back = strip(back.curriculum_training())
+    assert json.loads(json.dumps(h_back)) == json.loads(json.dumps(h_full))
+    for a, b in zip(back._engine.get_tables(), full._engine.get_tables()):
+        np.testing.assert_array_equal(a, b)
+    full._engine.close(); back._engine.close()
