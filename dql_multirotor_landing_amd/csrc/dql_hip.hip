@@ -183,6 +183,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
   return q;
 }
 
+#define DQL_ZERO_COPY_ENVS 16384  // up to here dql_step's kernel reads the host actions from pinned memory itself (no copy command)
 #define DQL_MAX_PERIODS 16  // agent periods one launch may run back to back per env (option "periods_per_launch")
 template <typename T> struct StepArgs {
   SimK<T> c;
@@ -584,6 +585,39 @@ __global__ void k_update_resident(double* qa, double* qb, double* count, const A
   tail->next_action = agent_predict((const double*)qa, (const double*)qb, in[n - 1].ns);
   __threadfence_system();
 }
+// one transition, arguments by value (dql_agent_mirror_update): nothing to read over PCIe, one record to write.  The arithmetic of
+// agent_update_one + agent_predict, spelled so that all eight table reads (both tables' row of the next state, the cell, its counter) are
+// independent and issue together: on an otherwise idle GPU each dependent read is a full trip to HBM, and five of them were the kernel.
+// `seq`: the call's sequence number, stored LAST (system-scope release): the host reads the record as soon as it sees the number, without
+// waiting for the stream to report the kernel complete (wait_posted)
+struct AgentOneOut { double q_new, count_new; int next_action; unsigned seq; };
+__global__ void k_update_one(double* qa, double* qb, double* count, int sa, int ns, double alpha, double gamma, double reward, uint32_t quirks, int coin, int done, AgentOneOut* out, unsigned seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const bool dbl = !(quirks & DQL_Q_UPDATE_TABLE_A_ONLY);
+  const bool sel_b = dbl && coin != 0;
+  double ra[3], rb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { ra[k] = qa[ns * 3 + k]; rb[k] = qb[ns * 3 + k]; }
+  double* qsel = sel_b ? qb : qa;
+  const double cur = qsel[sa], cnt = count[sa] + 1;
+  const bool val_b = dbl && !sel_b;  // the table that values the greedy action: the other one (Double Q-learning) or Q_table_a itself (B2)
+  const int b = sel_b ? argmax3(rb[0], rb[1], rb[2]) : argmax3(ra[0], ra[1], ra[2]);
+  const double va = b == 0 ? ra[0] : (b == 1 ? ra[1] : ra[2]), vb = b == 0 ? rb[0] : (b == 1 ? rb[1] : rb[2]);
+  const double best = val_b ? vb : va;
+  const int mask = (quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) ? (idx_pos(sa / 3) != idx_pos(ns)) : !done;
+  const double loss = alpha * (reward + (gamma * best) * (double)mask - cur);
+  const double q_new = cur + loss;
+  qsel[sa] = q_new; count[sa] = cnt;
+  if (sa / 3 == ns) {  // the next state's row contains the updated cell
+    const int k = sa % 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (j == k) { if (sel_b) rb[j] = q_new; else ra[j] = q_new; }
+  }
+  out->q_new = q_new; out->count_new = cnt;
+  out->next_action = argmax3((ra[0] + rb[0]) / 2, (ra[1] + rb[1]) / 2, (ra[2] + rb[2]) / 2);
+  __threadfence_system();
+  __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_predict_resident(const double* qa, const double* qb, const int* idx, long long n, uint8_t* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)agent_predict(qa, qb, idx[i]);
@@ -591,15 +625,22 @@ __global__ void k_predict_resident(const double* qa, const double* qb, const int
 }
 // what TrainingLandingEnv.step returns, gathered per env into pinned host memory (dql_step_outputs)
 struct StepOutRec { int idx_x, idx_y, step_count, code_flags; double reward, cum; };
-template <typename T> __global__ void k_step_outputs(const Quad<T>* __restrict__ sr, const int4* __restrict__ si, long long n, StepOutRec* out) {
+template <typename T> __global__ void k_step_outputs(const Quad<T>* __restrict__ sr, const int4* __restrict__ si, long long n, StepOutRec* out,
+                                                      const unsigned long long* bad_src, unsigned long long* bad_dst, unsigned* posted, unsigned seq) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int4 iv = si[i];
-  StepOutRec r;
-  r.idx_x = iv.x; r.idx_y = iv.y; r.step_count = iv.z & 0xffff; r.code_flags = iv.w & 0xffff;
-  r.reward = (double)sr[14 * n + i].a; r.cum = (double)sr[10 * n + i].b;
-  out[i] = r;
+  if (i < n) {
+    const int4 iv = si[i];
+    StepOutRec r;
+    r.idx_x = iv.x; r.idx_y = iv.y; r.step_count = iv.z & 0xffff; r.code_flags = iv.w & 0xffff;
+    r.reward = (double)sr[14 * n + i].a; r.cum = (double)sr[10 * n + i].b;
+    out[i] = r;
+  }
+  if (i == 0) *bad_dst = *bad_src;  // StatsDev::bad_actions rides along: no copy-engine command between the kernel and the wait
   __threadfence_system();
+  if (posted) {  // single-workgroup grids only (wave-uniform): every record of the workgroup is out before the number is
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(posted, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -693,9 +734,10 @@ struct dql_ctx {
   bool lit_ok = false;  // float32 and the tick constants are bit-identical to dql_refk.inc
   unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
   int elog_cap = 0, elog_n = 0;
-  uint8_t* h_actions = nullptr;  // pinned staging of dql_step's host actions (their copy to the device is asynchronous)
-  hipEvent_t ev_actions = nullptr; bool actions_in_flight = false;
-  void* h_out = nullptr; void* h_out_dev = nullptr;  // pinned, device-visible: StepOutRec[n] of dql_step_outputs
+  uint8_t* h_actions = nullptr; void* h_actions_dev = nullptr;  // pinned, device-visible staging of dql_step's host actions
+  hipEvent_t ev_actions = nullptr; bool actions_in_flight = false, actions_zero_copy = false;
+  void* h_out = nullptr; void* h_out_dev = nullptr;  // pinned, device-visible: StepOutRec[n] of dql_step_outputs, bad-action count, posted number
+  unsigned out_seq = 0;
   uint8_t* d_mask = nullptr;     // reset mask staging (dql_reset), allocated on first use
   const uint8_t* ext_actions = nullptr;  // caller-owned device actions of the next external step (dql_step_dev), else d_actions
   long long window_launches = 0; // training launches whose accumulators the window holds (windowed mode)
@@ -1028,6 +1070,17 @@ static hipError_t wait_stream(hipStream_t st) {
   }
   return hipStreamSynchronize(st);
 }
+// Completion of a single-workgroup kernel as seen through coherent pinned memory: its last act is a system-scope release store of the
+// call's sequence number next to its results.  Seeing the number is enough to read them — several microseconds before the stream reports
+// the kernel complete (end-of-kernel cache maintenance, completion signal, the runtime's bookkeeping), which is what a caller stepping ONE
+// env pays per call.  Bounded: false -> the caller falls back to the stream.
+static bool wait_posted(const unsigned* flag, unsigned seq) {
+  for (int i = 0; i < 400000; ++i) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+    __builtin_ia32_pause();
+  }
+  return false;
+}
 int dql_sync(dql_ctx* x) { CHECK_CTX(x); HIP_TRY(hipSetDevice(x->device)); HIP_TRY(wait_stream(x->stream)); return DQL_OK; }
 int dql_n_envs(dql_ctx* x, int64_t* n) { CHECK_CTX(x); if (!n) return fail(DQL_EINVAL, "null pointer"); *n = x->n; return DQL_OK; }
 int dql_state_bytes_per_env(dql_ctx* x, int64_t* bytes) {
@@ -1087,19 +1140,33 @@ int dql_step(dql_ctx* x, const uint8_t* actions) {
   CHECK_CTX(x);
   if (!actions) return fail(DQL_EINVAL, "actions must not be null (use dql_train_steps / dql_eval_steps for on-device action selection)");
   HIP_TRY(hipSetDevice(x->device));
-  // staged through pinned memory: the copy to the device is asynchronous, the caller's buffer is free on return, and nobody waits — except
-  // for the PREVIOUS step's copy out of the same staging buffer, which has long run by the time a caller comes back with new actions
+  // staged through pinned memory: the caller's buffer is free on return and nobody waits — except for the PREVIOUS step's read of the
+  // same staging buffer, which has long happened by the time a caller comes back with new actions.  Up to DQL_ZERO_COPY_ENVS envs the
+  // step kernel reads the staging buffer itself (one byte per lane over PCIe: no copy-engine command in front of the kernel — at one env
+  // that command costs more than the kernel); larger batches are copied to the device asynchronously first.
   if (!x->h_actions) {
-    if (hipHostMalloc((void**)&x->h_actions, (size_t)x->n, hipHostMallocDefault) != hipSuccess) { x->h_actions = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(action staging) failed"); }
+    if (hipHostMalloc((void**)&x->h_actions, (size_t)x->n, hipHostMallocMapped) != hipSuccess) { x->h_actions = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(action staging) failed"); }
+    HIP_TRY(hipHostGetDevicePointer(&x->h_actions_dev, x->h_actions, 0));
     HIP_TRY(hipEventCreateWithFlags(&x->ev_actions, hipEventDisableTiming));
   }
-  if (x->actions_in_flight) { HIP_TRY(hipEventSynchronize(x->ev_actions)); x->actions_in_flight = false; }
+  if (x->actions_in_flight) {
+    if (x->actions_zero_copy) HIP_TRY(wait_stream(x->stream));  // the kernel that reads the buffer (dql_step_outputs has normally waited for it already)
+    else HIP_TRY(hipEventSynchronize(x->ev_actions));
+    x->actions_in_flight = false;
+  }
   memcpy(x->h_actions, actions, (size_t)x->n);
-  HIP_TRY(hipMemcpyAsync(x->d_actions, x->h_actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipEventRecord(x->ev_actions, x->stream));
+  x->actions_zero_copy = x->n <= DQL_ZERO_COPY_ENVS;
+  if (x->actions_zero_copy) {
+    x->ext_actions = (const uint8_t*)x->h_actions_dev;
+  } else {
+    HIP_TRY(hipMemcpyAsync(x->d_actions, x->h_actions, (size_t)x->n, hipMemcpyHostToDevice, x->stream));
+    HIP_TRY(hipEventRecord(x->ev_actions, x->stream));
+    x->ext_actions = nullptr;
+  }
   x->actions_in_flight = true;
+  const int rc = launch_period(x, MODE_EXTERNAL, 0.0);  // the kernel checks the action codes (StatsDev::bad_actions)
   x->ext_actions = nullptr;
-  return launch_period(x, MODE_EXTERNAL, 0.0);  // the kernel checks the action codes (StatsDev::bad_actions)
+  return rc;
 }
 // out-of-range external actions seen by the step kernel since the last report: reported ONCE (the counter is cleared)
 static int report_bad_actions(dql_ctx* x, unsigned long long bad) {
@@ -1112,16 +1179,21 @@ int dql_step_outputs(dql_ctx* x, int32_t* idx_x, int32_t* idx_y, double* reward,
   HIP_TRY(hipSetDevice(x->device));
   const size_t n = (size_t)x->n;
   if (!x->h_out) {
-    if (hipHostMalloc(&x->h_out, n * sizeof(StepOutRec) + sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { x->h_out = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(step outputs) failed"); }
+    if (hipHostMalloc(&x->h_out, n * sizeof(StepOutRec) + 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { x->h_out = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(step outputs) failed"); }
     HIP_TRY(hipHostGetDevicePointer(&x->h_out_dev, x->h_out, 0));
+    memset((char*)x->h_out + n * sizeof(StepOutRec), 0, 2 * sizeof(unsigned long long));
   }
   const unsigned grid = (unsigned)((n + 255) / 256);
-  if (x->dtype == DQL_F32) hipLaunchKernelGGL(k_step_outputs<float>, dim3(grid), dim3(256), 0, x->stream, (const Quad<float>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev);
-  else hipLaunchKernelGGL(k_step_outputs<double>, dim3(grid), dim3(256), 0, x->stream, (const Quad<double>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev);
-  HIP_TRY(hipGetLastError());
   unsigned long long* bad_h = (unsigned long long*)((char*)x->h_out + n * sizeof(StepOutRec));
-  HIP_TRY(hipMemcpyAsync(bad_h, (char*)x->stats + offsetof(StatsDev, bad_actions), sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(wait_stream(x->stream));
+  unsigned long long* bad_d = (unsigned long long*)((char*)x->h_out_dev + n * sizeof(StepOutRec));
+  const unsigned long long* bad_src = (const unsigned long long*)((const char*)x->stats + offsetof(StatsDev, bad_actions));
+  const unsigned seq = ++x->out_seq;
+  unsigned* posted_d = grid == 1 ? (unsigned*)(bad_d + 1) : nullptr;
+  if (x->dtype == DQL_F32) hipLaunchKernelGGL(k_step_outputs<float>, dim3(grid), dim3(256), 0, x->stream, (const Quad<float>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev, bad_src, bad_d, posted_d, seq);
+  else hipLaunchKernelGGL(k_step_outputs<double>, dim3(grid), dim3(256), 0, x->stream, (const Quad<double>*)x->sr, (const int4*)x->si, (long long)n, (StepOutRec*)x->h_out_dev, bad_src, bad_d, posted_d, seq);
+  HIP_TRY(hipGetLastError());
+  if (!(posted_d && wait_posted((const unsigned*)(bad_h + 1), seq))) HIP_TRY(wait_stream(x->stream));
+  if (x->actions_zero_copy) x->actions_in_flight = false;  // the kernel that read the staged actions has run
   const StepOutRec* r = (const StepOutRec*)x->h_out;
   for (size_t i = 0; i < n; ++i) {
     const int fl = (r[i].code_flags >> 8) & 0xff;
@@ -1667,12 +1739,19 @@ struct dql_agent {
   double *qa = nullptr, *qb = nullptr, *count = nullptr;
   hipStream_t stream = nullptr;
   void* pin = nullptr; void* pin_dev = nullptr; size_t pin_bytes = 0;  // pinned + device-visible: arguments in, results out
+  // dql_agent_mirror_*: what the device tables hold, as the caller's arrays would have to look ([3][DQL_N_CELLS], pinned), and the answer
+  // the last update left for the next predict
+  double* shadow = nullptr; bool shadow_valid = false; int shadow_levels = 0;
+  int next_idx = -1, next_action = 0;
+  unsigned seq = 0;
+  void* post = nullptr; void* post_dev = nullptr;  // the mirror calls' own pinned page: [0] AgentOneOut, [64] predict's index, [128] its answer
 };
 static int agent_pin(dql_agent* a, size_t bytes) {
   if (bytes <= a->pin_bytes) return DQL_OK;
   if (a->pin) { HIP_TRY(hipStreamSynchronize(a->stream)); HIP_TRY(hipHostFree(a->pin)); a->pin = nullptr; a->pin_bytes = 0; }
   bytes = (bytes + 4095) & ~(size_t)4095;
-  if (hipHostMalloc(&a->pin, bytes, hipHostMallocMapped) != hipSuccess) { a->pin = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(agent staging) failed"); }
+  if (hipHostMalloc(&a->pin, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { a->pin = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(agent staging) failed"); }
+  memset(a->pin, 0, bytes);
   HIP_TRY(hipHostGetDevicePointer(&a->pin_dev, a->pin, 0));
   a->pin_bytes = bytes;
   return DQL_OK;
@@ -1691,6 +1770,10 @@ int dql_agent_create(int device, dql_agent** out) {
     if (hipMalloc((void**)&a->qa, B) != hipSuccess || hipMalloc((void**)&a->qb, B) != hipSuccess || hipMalloc((void**)&a->count, B) != hipSuccess) { rc = fail(DQL_ENOMEM, "hipMalloc failed"); break; }
     if (hipMemsetAsync(a->qa, 0, B, a->stream) != hipSuccess || hipMemsetAsync(a->qb, 0, B, a->stream) != hipSuccess || hipMemsetAsync(a->count, 0, B, a->stream) != hipSuccess) { rc = fail(DQL_EHIP, "hipMemset failed"); break; }
     rc = agent_pin(a, 4096);
+    if (rc) break;
+    if (hipHostMalloc(&a->post, 4096, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { a->post = nullptr; rc = fail(DQL_ENOMEM, "hipHostMalloc(agent results) failed"); break; }
+    memset(a->post, 0, 4096);
+    if (hipHostGetDevicePointer(&a->post_dev, a->post, 0) != hipSuccess) { rc = fail(DQL_EHIP, "hipHostGetDevicePointer failed"); break; }
   } while (0);
   if (rc) { const std::string why = g_err; dql_agent_destroy(a); return fail(rc, why); }
   *out = a;
@@ -1704,6 +1787,8 @@ int dql_agent_destroy(dql_agent* a) {
   if (a->qb) (void)hipFree(a->qb);
   if (a->count) (void)hipFree(a->count);
   if (a->pin) (void)hipHostFree(a->pin);
+  if (a->shadow) (void)hipHostFree(a->shadow);
+  if (a->post) (void)hipHostFree(a->post);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
   return DQL_OK;
@@ -1716,6 +1801,7 @@ int dql_agent_set_tables(dql_agent* a, const double* qa, const double* qb, const
   if (qb) HIP_TRY(hipMemcpyAsync(a->qb, qb, B, hipMemcpyHostToDevice, a->stream));
   if (count) HIP_TRY(hipMemcpyAsync(a->count, count, B, hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));  // the caller's arrays may change right after return
+  a->shadow_valid = false; a->next_idx = -1;
   return DQL_OK;
 }
 int dql_agent_get_tables(dql_agent* a, double* qa, double* qb, double* count) {
@@ -1763,6 +1849,62 @@ int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns
   const AgentUpdOut* o = (const AgentUpdOut*)((const char*)a->pin + in_b);
   for (int64_t i = 0; i < n; ++i) { if (q_new) q_new[i] = o[i].q_new; if (count_new) count_new[i] = o[i].count_new; }
   if (next_action) *next_action = (uint8_t)((const AgentUpdTail*)(o + n))->next_action;
+  a->shadow_valid = false; a->next_idx = -1;
+  return DQL_OK;
+}
+// ---- host-mirrored single transitions ----
+// brings the device tables up to the caller's arrays; what changed is found by comparing with the shadow of the last upload
+static int mirror_refresh(dql_agent* a, const double* qa, const double* qb, const double* count, int32_t n_levels) {
+  if (!qa || !qb || !count) return fail(DQL_EINVAL, "null table");
+  if (n_levels < 1 || n_levels > DQL_MAX_LEVELS) return fail(DQL_EINVAL, "n_levels must be in 1..5");
+  HIP_TRY(hipSetDevice(a->device));
+  const size_t B = DQL_N_CELLS * sizeof(double), used = (size_t)n_levels * DQL_STATES_PER_LEVEL * 3 * sizeof(double);
+  if (!a->shadow) {
+    if (hipHostMalloc((void**)&a->shadow, 3 * B, hipHostMallocDefault) != hipSuccess) { a->shadow = nullptr; return fail(DQL_ENOMEM, "hipHostMalloc(table shadow) failed"); }
+    a->shadow_valid = false;
+  }
+  const double* host[3] = {qa, qb, count};
+  double* dev[3] = {a->qa, a->qb, a->count};
+  bool sent = false;
+  for (int t = 0; t < 3; ++t) {
+    double* sh = a->shadow + (size_t)t * DQL_N_CELLS;
+    if (a->shadow_valid && a->shadow_levels == n_levels && memcmp(sh, host[t], used) == 0) continue;
+    memcpy(sh, host[t], used);
+    memset((char*)sh + used, 0, B - used);
+    HIP_TRY(hipMemcpyAsync(dev[t], sh, B, hipMemcpyHostToDevice, a->stream));
+    sent = true;
+  }
+  if (sent) { HIP_TRY(hipStreamSynchronize(a->stream)); a->next_idx = -1; }  // the shadow may be patched right after return
+  a->shadow_valid = true; a->shadow_levels = n_levels;
+  return DQL_OK;
+}
+int dql_agent_mirror_predict(dql_agent* a, const double* qa, const double* qb, const double* count, int32_t n_levels, int32_t idx, uint8_t* action_out) {
+  CHECK_AGENT(a);
+  if (!action_out) return fail(DQL_EINVAL, "null action_out");
+  { int rc = mirror_refresh(a, qa, qb, count, n_levels); if (rc) return rc; }
+  if (idx < 0 || idx >= n_levels * DQL_STATES_PER_LEVEL) return fail(DQL_EINVAL, "state index outside the table's levels");
+  if (idx == a->next_idx) { *action_out = (uint8_t)a->next_action; return DQL_OK; }  // the last update's kernel answered this on the tables as they are
+  *(int*)((char*)a->post + 64) = idx;
+  hipLaunchKernelGGL(k_predict_resident, dim3(1), dim3(64), 0, a->stream, (const double*)a->qa, (const double*)a->qb, (const int*)((char*)a->post_dev + 64), 1ll, (uint8_t*)a->post_dev + 128);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(wait_stream(a->stream));
+  *action_out = *((const uint8_t*)a->post + 128);
+  return DQL_OK;
+}
+int dql_agent_mirror_update(dql_agent* a, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha, double gamma,
+                            double reward, uint32_t quirks, int32_t coin, int32_t done) {
+  CHECK_AGENT(a);
+  { int rc = mirror_refresh(a, qa, qb, count, n_levels); if (rc) return rc; }
+  if (sa < 0 || sa >= n_levels * DQL_STATES_PER_LEVEL * 3 || ns < 0 || ns >= n_levels * DQL_STATES_PER_LEVEL) return fail(DQL_EINVAL, "index outside the table's levels");
+  AgentOneOut* o = (AgentOneOut*)a->post;
+  const unsigned seq = ++a->seq;
+  hipLaunchKernelGGL(k_update_one, dim3(1), dim3(64), 0, a->stream, a->qa, a->qb, a->count, (int)sa, (int)ns, alpha, gamma, reward, quirks, (int)coin, (int)done, (AgentOneOut*)a->post_dev, seq);
+  HIP_TRY(hipGetLastError());
+  if (!wait_posted(&o->seq, seq)) HIP_TRY(wait_stream(a->stream));
+  const int t = (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && coin) ? 1 : 0;  // the table agent_update_one wrote
+  (t ? qb : qa)[sa] = o->q_new; count[sa] = o->count_new;
+  a->shadow[(size_t)t * DQL_N_CELLS + sa] = o->q_new; a->shadow[(size_t)2 * DQL_N_CELLS + sa] = o->count_new;
+  a->next_idx = ns; a->next_action = o->next_action;
   return DQL_OK;
 }
 

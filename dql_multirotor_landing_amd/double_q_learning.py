@@ -1,6 +1,7 @@
 """Drop-in mirror of the reference's `double_q_learning.py` (pkg/double_q_learning.py:32-146): same class,
 attributes, methods, file names and `.npy` layout.  The table arithmetic (argmax, TD update, transfer scaling) runs
-on the device through the C ABI (`dql_agent_predict`, `dql_agent_update`, `dql_agent_transfer`); the host draws the
+on the device through the C ABI (`dql_agent_mirror_predict`, `dql_agent_mirror_update` on tables resident on the device and
+mirrored from the public host arrays, `dql_agent_transfer`); the host draws the
 reference's `np.random` numbers so that a seeded run consumes the global MT19937 stream exactly as the reference
 does (B1, B4)."""
 from __future__ import annotations
@@ -15,7 +16,6 @@ import ctypes as C
 
 from . import _lib, ops
 from .config import MAX_LEVELS, N_CELLS, Q_PAPER, Q_REFERENCE, TABLE_SHAPE
-from .mdp import pack_state
 
 State = Tuple[int, int, int, int, int]
 StateAction = Tuple[int, int, int, int, int, int]
@@ -44,13 +44,16 @@ class DoubleQLearningAgent:
         self._device = device
         self._lib = None
         self._res = None      # dql_agent*: the tables resident on the device between calls (created on first use)
-        self._shadow = None   # what the device holds, padded to 5 levels: (qa, qb, count)
-        self._next = None     # (packed state, greedy action) the last update's kernel computed for its next state, on the tables as they are now
+        self._bound = None    # (Q_table_a, Q_table_b, state_action_counter) objects whose buffer addresses self._ptrs holds
+        self._ptrs = None
 
-    # ---- resident device tables (include/dql.h dql_agent_*) ----
+    # ---- resident device tables, mirrored from the public host arrays (include/dql.h dql_agent_mirror_*) ----
     def _resident(self):
-        """The device copy of the tables, brought up to date if the host arrays were written since (they are public attributes: the
-        comparison against the shadow of what was last uploaded IS the dirty flag — 3 x 22 KB of memcmp instead of 3 x 22 KB over PCIe)."""
+        """(lib, agent handle, the three table pointers, level count).  The host arrays are public attributes that callers read, write
+        and replace: the library compares them with what the device holds on every call (memcmp against its shadow, ~1 us a table) and
+        uploads what differs — the comparison IS the dirty flag.  Here only the buffer addresses are kept, and taken again when an
+        attribute was rebound to another array (anything that is not writable C-order float64 of the table's shape is replaced by such
+        a copy first, as `np.save` / the device would see it)."""
         lib = self._lib
         if lib is None:
             lib = self._lib = _lib.load()
@@ -58,19 +61,23 @@ class DoubleQLearningAgent:
             h = C.c_void_p()
             _lib.check(lib.dql_agent_create(self._device, C.byref(h)))
             self._res = h
-            # call arguments and results of the single-transition calls: allocated (and their pointers taken) once
-            io = self._io = {"idx": np.zeros(1, np.int32), "act": np.zeros(1, np.uint8), "sa": np.zeros(1, np.int32), "ns": np.zeros(1, np.int32),
-                             "alpha": np.zeros(1), "reward": np.zeros(1), "coin": np.zeros(1, np.uint8), "done": np.zeros(1, np.uint8),
-                             "q_new": np.zeros(1), "c_new": np.zeros(1)}
-            self._ptr = {k: v.ctypes.data_as(C.c_void_p) for k, v in io.items()}
-        host = (self.Q_table_a, self.Q_table_b, self.state_action_counter)
-        n = self.curriculum_steps
-        sh = self._shadow
-        if sh is None or not all(a.shape == (n,) + TABLE_SHAPE[1:] and np.array_equal(a, b.reshape(TABLE_SHAPE)[:n]) for a, b in zip(host, sh)):
-            sh = self._shadow = self._padded()
-            _lib.check(lib.dql_agent_set_tables(self._res, *[a.ctypes.data_as(C.c_void_p) for a in sh]))
-            self._next = None  # the host wrote the tables: what the last update predicted for its next state no longer holds
-        return lib, self._res
+            self._act = C.c_uint8(0)
+            self._act_ref = C.byref(self._act)
+        a, b, c = self.Q_table_a, self.Q_table_b, self.state_action_counter
+        bound = self._bound
+        if bound is None or a is not bound[0] or b is not bound[1] or c is not bound[2]:
+            shape = (self.curriculum_steps,) + TABLE_SHAPE[1:]
+            fixed = []
+            for t in (a, b, c):
+                if not (isinstance(t, np.ndarray) and t.dtype == np.float64 and t.flags.c_contiguous and t.flags.writeable and t.flags.aligned):
+                    t = np.array(t, dtype=np.float64, order="C")
+                if t.shape != shape:
+                    raise ValueError(f"table of shape {t.shape}, expected {shape}")
+                fixed.append(t)
+            a, b, c = self.Q_table_a, self.Q_table_b, self.state_action_counter = fixed
+            self._bound = (a, b, c)
+            self._ptrs = tuple(t.ctypes.data for t in fixed)
+        return lib, self._res, self._ptrs, self.curriculum_steps
 
     def close(self):
         if getattr(self, "_res", None):
@@ -123,14 +130,23 @@ class DoubleQLearningAgent:
         self.Q_table_b = qb.reshape(TABLE_SHAPE)[:n].copy()
         self.state_action_counter = cnt.reshape(TABLE_SHAPE)[:n].copy()
 
+    _DIMS = (None, 3, 3, 3, 7, 3)
+
     def _check_state(self, state, n):
+        """numpy's index semantics for the tuple (IndexError out of bounds, negative indices wrap), returned as plain ints"""
         if len(state) != n:
             raise IndexError(f"expected an index tuple of length {n}")
-        dims = (self.curriculum_steps, 3, 3, 3, 7, 3)[:n]
-        for v, d in zip(state, dims):
-            if not -d <= int(v) < d:
-                raise IndexError(f"index {v} is out of bounds for axis with size {d}")
-        return tuple(int(v) % d for v, d in zip(state, dims))
+        out = []
+        d = self.curriculum_steps
+        for k in range(n):
+            v = int(state[k])
+            if not 0 <= v < d:
+                if not -d <= v < 0:
+                    raise IndexError(f"index {v} is out of bounds for axis with size {d}")
+                v += d
+            out.append(v)
+            d = self._DIMS[k + 1] if k + 1 < 6 else 0
+        return tuple(out)
 
     # ---- pkg/double_q_learning.py:77-89 ----
     def transfer_learning(self, current_curriculum_step: int, transfer_learning_ratio: float):
@@ -153,38 +169,31 @@ class DoubleQLearningAgent:
         sa = self._check_state(current_state_action, 6)
         ns = self._check_state(next_state, 5)
         u = np.random.uniform(0, 1)  # reference: drawn and ignored, both arms select Q_table_a (B1); paper mode: the coin
-        lib, res = self._resident()
-        cell = pack_state(sa[:5]) * 3 + sa[5]
-        io, p = self._io, self._ptr
-        io["sa"][0] = cell; io["ns"][0] = pack_state(ns); io["alpha"][0] = alpha; io["reward"][0] = reward
-        sel_b = False
+        lib, res, (pa, pb, pc), n = self._resident()
+        cell = ((((sa[0] * 3 + sa[1]) * 3 + sa[2]) * 3 + sa[3]) * 7 + sa[4]) * 3 + sa[5]
+        nidx = (((ns[0] * 3 + ns[1]) * 3 + ns[2]) * 3 + ns[3]) * 7 + ns[4]
+        # the library patches the one changed cell and its visit counter into Q_table_a / _b / state_action_counter itself
         if self.mode == "reference":
-            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_REFERENCE, None, None, p["q_new"], p["c_new"], p["act"]))
+            rc = lib.dql_agent_mirror_update(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_REFERENCE, 0, 0)
         else:
-            sel_b = not u < 0.5
-            io["coin"][0] = 1 if sel_b else 0; io["done"][0] = 1 if done else 0
-            _lib.check(lib.dql_agent_update_resident(res, p["sa"], p["ns"], p["alpha"], float(gamma), p["reward"], 1, Q_PAPER, p["coin"], p["done"], p["q_new"], p["c_new"], p["act"]))
-        # the kernel reports the one cell it changed and its visit counter: patch the host arrays and the shadow of the device copy
-        q_new, c_new = float(io["q_new"][0]), float(io["c_new"][0])
-        (self.Q_table_b if sel_b else self.Q_table_a)[sa] = q_new
-        self.state_action_counter[sa] = c_new
-        self._shadow[1 if sel_b else 0][cell] = q_new
-        self._shadow[2][cell] = c_new
-        self._next = (int(io["ns"][0]), int(io["act"][0]))
+            rc = lib.dql_agent_mirror_update(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_PAPER, 0 if u < 0.5 else 1, 1 if done else 0)
+        if rc:
+            _lib.check(rc)
 
     # ---- pkg/double_q_learning.py:110-124 ----
     def guess(self, state: State, exploration_rate: float):
         explore = np.random.uniform(0, 1) < exploration_rate
-        return int(np.where(explore, np.random.randint(3), self.predict(state)))  # randint always drawn (B4)
+        rnd = np.random.randint(3)  # always drawn (B4: np.where evaluates both arms)
+        greedy = self.predict(state)
+        return int(rnd) if explore else greedy
 
     def predict(self, state: State):
         s = self._check_state(state, 5)
-        lib, res = self._resident()   # (re-uploads and forgets self._next if the host arrays were written)
-        idx = pack_state(s)
-        if self._next is not None and self._next[0] == idx:
-            return self._next[1]        # the update kernel already answered this on the current tables
-        self._io["idx"][0] = idx
-        _lib.check(lib.dql_agent_predict_resident(res, self._ptr["idx"], 1, self._ptr["act"]))
-        return int(self._io["act"][0])
+        lib, res, (pa, pb, pc), n = self._resident()
+        # answered from the last update's kernel when that update's next state is asked for and the tables were not written since
+        rc = lib.dql_agent_mirror_predict(res, pa, pb, pc, n, (((s[0] * 3 + s[1]) * 3 + s[2]) * 3 + s[3]) * 7 + s[4], self._act_ref)
+        if rc:
+            _lib.check(rc)
+        return self._act.value
 
     get_action = guess  # name used by BASELINE.json's north_star

@@ -162,7 +162,9 @@ class Trainer:
         if counter == 0:
             self._alpha = self._alpha_min
         else:
-            self._alpha = float(np.max([np.float_power(1 / (counter), self._omega), self._alpha_min]))
+            # = np.max([np.float_power(1 / counter, omega), alpha_min]) of the reference (pkg/trainer.py:95) without building the list's array:
+            # max() keeps a NaN first argument, as np.max does
+            self._alpha = float(max(np.float_power(1 / (counter), self._omega), self._alpha_min))
         if math.isnan(self._alpha):
             raise ValueError(f"Leaning rate cannot be NaN, {counter}, {self._omega}, {self._alpha_min}")
         return self._alpha

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DQL_ABI_VERSION 3
+#define DQL_ABI_VERSION 4
 
 typedef enum dql_status {
   DQL_OK = 0,
@@ -373,6 +373,18 @@ int dql_agent_update_resident(dql_agent* agent, const int32_t* sa, const int32_t
                               int64_t n, uint32_t quirks, const uint8_t* coin_or_null, const uint8_t* done_or_null, double* q_new_out,
                               double* count_new_out, uint8_t* next_action_out_or_null /* predict(ns[n-1]) on the updated tables: the
                               reference's loop (pkg/trainer.py:191-212) asks for exactly that next, and gets it without a second round trip */);
+/* The resident agent driven the way the reference's loop drives it (pkg/trainer.py:191-212) — ONE transition per call — against tables
+ * that live in the CALLER's arrays (DoubleQLearningAgent.Q_table_a / Q_table_b / state_action_counter: float64, C order,
+ * [n_levels][3][3][3][7][3], public and writable at any time).  Every call first compares the caller's three arrays with what the device
+ * holds (memcmp against a pinned host shadow, ~1 us per table) and uploads what differs: writes between calls are honoured without a
+ * dirty flag.  dql_agent_mirror_update applies pkg/double_q_learning.py:91-146 to the one transition (sa = cell index idx * 3 + action,
+ * ns = packed next state; quirks / coin / done as in dql_agent_update) and patches the ONE changed cell and its visit counter into the
+ * caller's arrays itself; it also keeps predict(ns) on the updated tables, which dql_agent_mirror_predict hands out without a device round
+ * trip when asked for exactly that state next (as the reference's loop does) and the tables were not written in between.
+ * Levels n_levels..4 of the device tables are zero.  DQL_EINVAL: null array, n_levels outside 1..5, index outside the n_levels levels. */
+int dql_agent_mirror_predict(dql_agent* agent, const double* qa, const double* qb, const double* count, int32_t n_levels, int32_t idx, uint8_t* action_out);
+int dql_agent_mirror_update(dql_agent* agent, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha,
+                            double gamma, double reward, uint32_t quirks, int32_t coin, int32_t done);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.SYMBOLS), f"header vs binding: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dql_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.dql_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_config_layout_and_defaults_match_c(lib):

@@ -319,3 +319,54 @@ def test_trainer_resume_on_the_hip_engine_equals_uninterrupted_run(tmp_path):
     for a, b in zip(back._engine.get_tables(), full._engine.get_tables()):
         np.testing.assert_array_equal(a, b)
     full._engine.close(); back._engine.close()
+
+
+def test_agent_tables_are_live_host_arrays():
+    """`Q_table_a / Q_table_b / state_action_counter` stay ordinary public arrays while the arithmetic runs on tables resident on the
+    device (include/dql.h dql_agent_mirror_*): cells written in place, attributes rebound to other arrays (any dtype / layout) and
+    tables of fewer than 5 levels are all honoured by the next call; every update lands in the host arrays; predict answers on the
+    tables as they are now — against the CPU oracle replaying the same sequence, both update rules."""
+    from dql_multirotor_landing_amd.config import Q_PAPER, Q_REFERENCE
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    for mode, quirks in (("reference", Q_REFERENCE), ("paper", Q_PAPER)):
+        for levels in (5, 3, 1):
+            np.random.seed(levels)
+            a = DoubleQLearningAgent(levels, mode=mode)
+            shape = (levels, 3, 3, 3, 7, 3)
+            a.Q_table_a = rng.normal(size=shape)
+            a.Q_table_b = rng.normal(size=shape).astype(np.float32)              # not float64: replaced by a float64 copy on first use
+            a.state_action_counter = np.asfortranarray(rng.integers(0, 9, shape).astype(np.float64))  # not C order: likewise
+            o = [np.zeros(2835), np.zeros(2835), np.zeros(2835)]
+            for k, t in enumerate((a.Q_table_a, a.Q_table_b, a.state_action_counter)):
+                o[k][:levels * 567] = np.asarray(t, dtype=np.float64).ravel()
+            ns = None
+            for i in range(150):
+                sa = tuple(int(rng.integers(0, d)) for d in shape)
+                if ns is not None and i % 3:
+                    sa = ns + (sa[5],)                                               # the loop's shape: the next transition starts where the last ended
+                ns = tuple(int(rng.integers(0, d)) for d in shape[:5])
+                if i % 17 == 5:
+                    a.Q_table_a[ns + (1,)] = 3.25; o[0][np.ravel_multi_index(ns + (1,), shape)] = 3.25      # written in place between calls
+                if i % 29 == 7:
+                    a.Q_table_b = a.Q_table_b * 0.5; o[1] *= 0.5                  # rebound to a new array
+                if i % 41 == 9:
+                    a.state_action_counter[...] = 0.0; o[2][:] = 0.0
+                alpha, reward, done = float(rng.uniform(0.02, 1.0)), float(rng.normal() * 5), bool(rng.integers(0, 2))
+                st = np.random.get_state(); coin = not np.random.uniform(0, 1) < 0.5; np.random.set_state(st)  # the draw update() is about to make
+                a.update(sa, ns, alpha, 0.99, reward, done=done)
+                orc.agent_update(o[0], o[1], o[2], np.array([np.ravel_multi_index(sa, shape)], np.int32), np.array([np.ravel_multi_index(ns, shape[:5])], np.int32),
+                                 np.array([alpha]), 0.99, np.array([reward]), quirks=quirks, coin=np.array([coin], np.uint8), done=np.array([done], np.uint8))
+                for got, want in zip((a.Q_table_a, a.Q_table_b, a.state_action_counter), o):
+                    assert got.dtype == np.float64 and got.shape == shape
+                    np.testing.assert_array_equal(got.ravel(), want[:levels * 567])
+                assert not any(w[levels * 567:].any() for w in o)
+                q = ns if i % 2 else tuple(int(rng.integers(0, d)) for d in shape[:5])
+                assert a.predict(q) == orc.agent_predict(o[0], o[1], np.array([np.ravel_multi_index(q, shape[:5])], np.int32))[0]
+            with pytest.raises(IndexError):
+                a.predict((levels, 0, 0, 0, 0))
+            a.Q_table_a = np.zeros((levels + 1, 3, 3, 3, 7, 3))
+            with pytest.raises(ValueError):
+                a.predict((0, 0, 0, 0, 0))
+            a.close()

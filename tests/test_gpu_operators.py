@@ -173,14 +173,16 @@ def test_resident_agent_equals_stateless_operators(ops):
         _lib.check(lib.dql_agent_destroy(h))
 
 
-def test_step_outputs_and_kernel_side_action_check():
+@pytest.mark.parametrize("n", [200, 300, 20000])
+def test_step_outputs_and_kernel_side_action_check(n):
     """dql_step_outputs == what the field getters say (state, reward, done, code, step count, cumulative reward, reset flag) in one round
     trip; an out-of-range action handed straight to the C ABI is flown as "hold" and reported ONCE by the next outputs / stats call —
-    the host no longer loops over the actions."""
+    the host no longer loops over the actions.  The three sizes take the three paths of the pair dql_step / dql_step_outputs: 200 — one
+    workgroup: actions read from pinned memory by the step kernel, results picked up when the kernel posts its sequence number; 300 —
+    several workgroups: the stream is waited for; 20 000 (> DQL_ZERO_COPY_ENVS) — actions copied to the device first."""
     import ctypes as C
     from dql_multirotor_landing_amd import _lib
     from dql_multirotor_landing_amd.engine import Engine
-    n = 300
     eng = Engine(DqlConfig(dtype=F64, t_max=2.0), n, seed=4)
     twin = Engine(DqlConfig(dtype=F64, t_max=2.0), n, seed=4)
     rng = np.random.default_rng(1)
