@@ -1065,9 +1065,17 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env
   return out;
 }
 
-#ifndef DQL_TICK_UNROLL
-#define DQL_TICK_UNROLL 2  // measured: -9 % at 1 M envs (fewer loop-carried moves); 3, 4, 6 are worse
+// Unroll factor of the plain tick loop.  float64: 2 (fewer loop-carried moves; 63.2 vs 65.0 us per period at 131 072 envs).  float32: that
+// held in rounds 1 - 2 (-9 % at 1 M envs) and stopped holding with the shorter round-3 tick: NOT unrolling is 5 - 6 % faster wherever
+// the plain / literal loop runs (in-run A/B, config 4 flags: 131 072 envs 24.7 vs 26.1 us, 262 144: 42.5 vs 45.0, 1 M: 150.2 vs 160.2;
+// unrolling by 3, 5, 7, 11 lands between the two)
+#ifndef DQL_TICK_UNROLL_F32
+#define DQL_TICK_UNROLL_F32 1
 #endif
+#ifndef DQL_TICK_UNROLL_F64
+#define DQL_TICK_UNROLL_F64 2
+#endif
+template <typename T> struct TickUnroll { static constexpr int n = sizeof(T) == 4 ? DQL_TICK_UNROLL_F32 : DQL_TICK_UNROLL_F64; };
 #ifndef DQL_GROUP
 #define DQL_GROUP 5  // manager_div of the reference: 500 Hz physics / 100 Hz observation
 #endif
@@ -1157,7 +1165,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
       physics_tick_pk(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
     };
     if constexpr (!HOT) {
-#pragma unroll DQL_TICK_UNROLL
+#pragma unroll TickUnroll<T>::n
       for (int i = 0; i < n_ticks; ++i) {
         tick_pk(phase == 0);
         phase = (phase + 1 == s.div) ? 0 : phase + 1;
@@ -1182,7 +1190,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     unpack_tick(ts, e);
   } else if constexpr (!(HOT && sizeof(T) == 4)) {
     // big batches (several waves per SIMD, registers decide the occupancy): the plain loop
-#pragma unroll DQL_TICK_UNROLL
+#pragma unroll TickUnroll<T>::n
     for (int i = 0; i < n_ticks; ++i) {
       DQL_SECTION("rot");
       quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
