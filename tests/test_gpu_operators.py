@@ -220,3 +220,30 @@ def test_float32_tick_square_root_is_correctly_rounded_on_its_whole_domain(ops):
     assert ops.selftest_sqrt(1e-30, 3.4028234663852886e38) == 0
     assert ops.selftest_sqrt(2.0 ** -102, 1e-30) == 0
     assert ops.selftest_sqrt(2.0 ** -126, 2.0 ** -104) > 0
+
+
+def test_agent_mirror_argument_checks():
+    """dql_agent_mirror_* refuse what would read or write outside the caller's tables (include/dql.h): null arrays, level counts outside
+    1..5, cells / states beyond the n_levels levels the arrays hold; a refused call changes nothing."""
+    import ctypes as C
+    from dql_multirotor_landing_amd import _lib
+    from dql_multirotor_landing_amd.config import Q_REFERENCE
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.dql_agent_create(0, C.byref(h)))
+    n = 3
+    qa, qb, cnt = np.zeros(n * 567), np.ones(n * 567), np.zeros(n * 567)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    act = C.c_uint8(9)
+    upd = lambda levels, sa, ns: lib.dql_agent_mirror_update(h, p(qa), p(qb), p(cnt), levels, sa, ns, 0.5, 0.99, 1.0, Q_REFERENCE, 0, 0)
+    assert lib.dql_agent_mirror_predict(h, None, p(qb), p(cnt), n, 0, C.byref(act)) == _lib.EINVAL
+    assert lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), 0, 0, C.byref(act)) == _lib.EINVAL
+    assert lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), 6, 0, C.byref(act)) == _lib.EINVAL
+    assert lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), n, n * 189, C.byref(act)) == _lib.EINVAL   # first state of level 3: not in a 3-level table
+    assert lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), n, -1, C.byref(act)) == _lib.EINVAL
+    assert lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), n, 0, None) == _lib.EINVAL
+    assert upd(n, n * 567, 0) == _lib.EINVAL and upd(n, 0, n * 189) == _lib.EINVAL and upd(n, -1, 0) == _lib.EINVAL and upd(7, 0, 0) == _lib.EINVAL
+    assert act.value == 9 and not qa.any() and not cnt.any()
+    _lib.check(upd(n, 5, 7)); _lib.check(lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), n, 7, C.byref(act)))
+    assert qa[5] == 0.5 * (1.0 + 0.99 * 0.0 * 0 - 0.0) and cnt[5] == 1.0 and act.value in (0, 1, 2)
+    _lib.check(lib.dql_agent_destroy(h))
