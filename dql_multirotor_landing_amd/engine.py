@@ -151,6 +151,12 @@ class Engine:
         _lib.check(self.lib.dql_get_tables(self._h, _p(qa), _p(qb), _p(cnt)))
         return qa.reshape(TABLE_SHAPE), qb.reshape(TABLE_SHAPE), cnt.reshape(TABLE_SHAPE)
 
+    def get_counts(self):
+        """the visit counter alone (what the Trainer's per-chunk learning-rate report needs): the same call as get_tables, one table over the bus"""
+        cnt = np.zeros(N_CELLS)
+        _lib.check(self.lib.dql_get_tables(self._h, None, None, _p(cnt)))
+        return cnt.reshape(TABLE_SHAPE)
+
     def set_tables(self, qa=None, qb=None, count=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ravel()
         qa, qb, count = f(qa), f(qb), f(count)

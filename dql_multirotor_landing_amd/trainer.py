@@ -423,7 +423,8 @@ class Trainer:
                 pw.reset(); order.reset()
                 episodes, steps, chunk_i = 0, 0, 0
             s_prev = eng.stats()
-            cnt_prev = np.asarray(eng.get_tables()[2], dtype=np.float64).copy()
+            counts = eng.get_counts if hasattr(eng, "get_counts") else (lambda: eng.get_tables()[2])
+            cnt_prev = np.asarray(counts(), dtype=np.float64).copy()
             t_level = time.perf_counter()
             promoted = False
             promoted_at = None
@@ -454,9 +455,9 @@ class Trainer:
                 w_ok = sum(o for _, o in window)
                 # the reference divides by the deque length limit (100) also while the deque is filling (:222-224)
                 rate = w_ok / max(w_eps, self._successive_successful_episodes)
-                cnt_now = np.asarray(eng.get_tables()[2], dtype=np.float64)
+                cnt_now = np.asarray(counts(), dtype=np.float64)
                 self._alpha = self._mean_alpha(cnt_prev, cnt_now)
-                cnt_prev = cnt_now.copy()
+                cnt_prev = cnt_now
                 info = {"Curent episode": episodes, "Remaining episodes": self._max_num_episodes - episodes + 1, "Exploration rate": eps,
                         "Learning rate": self._alpha, "Success rate": rate, "Mean reward": new_rew / max(1, new_dec),
                         "Cumulative reward": new_rew / max(1, new_eps), "Agent periods": steps, "Curriculum step": k,
@@ -495,23 +496,28 @@ class Trainer:
             else:  # max_steps_per_level (build-specific bound) hit: stop here
                 self.save()
                 break
+        fh = getattr(self, "_log_fh", None)
+        if fh is not None and not fh.closed:
+            fh.close()
         return self.history
 
     # ---- pkg/trainer.py:247-303: scalar log with the reference's tag names (CSV instead of one TensorBoard file per episode) ----
     def log(self, info: Dict[str, Any], clean=False):
         if self._rank != 0:
             return
-        path = self._save_path / "logs"
-        path.mkdir(parents=True, exist_ok=True)
-        f = path / "scalars.csv"
-        new = not f.exists()
-        term = info.get("Termination condition") or {}
-        with open(f, "a", newline="") as fh:
-            w = csv.writer(fh)
+        fh = getattr(self, "_log_fh", None)
+        if fh is None or fh.closed:  # opened once per Trainer (a row per chunk: open + close per row showed up in the loop's profile), flushed per row
+            path = self._save_path / "logs"
+            path.mkdir(parents=True, exist_ok=True)
+            f = path / "scalars.csv"
+            new = not f.exists()
+            fh = self._log_fh = open(f, "a", newline="")
             if new:
-                w.writerow(LOG_COLUMNS)
-            w.writerow([info.get("Curriculum step"), self._curriculum_episode_count, info.get("Curent episode"), info.get("Agent periods"),
-                        info.get("Success rate"), info.get("Cumulative reward"), info.get("Exploration rate"), info.get("Learning rate"),
-                        info.get("Mean reward")] + [term.get(c, 0) for c in _TERMINAL])
+                csv.writer(fh).writerow(LOG_COLUMNS)
+        term = info.get("Termination condition") or {}
+        csv.writer(fh).writerow([info.get("Curriculum step"), self._curriculum_episode_count, info.get("Curent episode"), info.get("Agent periods"),
+                                 info.get("Success rate"), info.get("Cumulative reward"), info.get("Exploration rate"), info.get("Learning rate"),
+                                 info.get("Mean reward")] + [term.get(c, 0) for c in _TERMINAL])
+        fh.flush()
         if not self._quiet:
             print(" | ".join(f"{k}: {v}" for k, v in info.items()), flush=True)

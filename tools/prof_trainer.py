@@ -11,7 +11,7 @@ from dql_multirotor_landing_amd.trainer import Trainer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 prof = len(sys.argv) > 2 and sys.argv[2] == "profile"
 with tempfile.TemporaryDirectory() as d:
-    tr = Trainer(n_envs=n, mode="paper", save_path=Path(d) / "run", dtype=F32, sync_period=bench.CURRICULUM_SYNC, max_num_episodes=384 * n, seed=42, **bench.CURRICULUM_KW)
+    tr = Trainer(n_envs=n, mode="paper", save_path=Path(d) / "run", dtype=F32, sync_period=bench.CURRICULUM_SYNC, max_num_episodes=384 * n, seed=42, checkpoint_every=10**9, **bench.CURRICULUM_KW)
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     if prof: pr.enable()
