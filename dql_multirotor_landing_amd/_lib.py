@@ -99,6 +99,7 @@ SYMBOLS = {
     "dql_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "dql_episode_log_enable": (C.c_int, [_vp, _i32]),
     "dql_episode_log_read": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "dql_episode_log_read_words": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_i32)]),
     "dql_discretise": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dql_manager_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _u64, _vp]),

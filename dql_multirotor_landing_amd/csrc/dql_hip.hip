@@ -1610,6 +1610,31 @@ int dql_episode_log_read(dql_ctx* x, uint64_t* done_masks, uint64_t* goal_masks,
   return DQL_OK;
 }
 
+// the same for the first n_words 64-env words of every period only (the promotion rule judges the first few global env ids: 1 KB per chunk
+// instead of 16 B per env)
+int dql_episode_log_read_words(dql_ctx* x, uint64_t* done_masks, uint64_t* goal_masks, int32_t max_periods, int32_t n_words, int32_t* n_periods) {
+  CHECK_CTX(x);
+  if (!x->elog) return fail(DQL_ESTATE, "episode log is not enabled (dql_episode_log_enable)");
+  if (!n_periods) return fail(DQL_EINVAL, "n_periods must not be null");
+  const size_t nw = (size_t)((x->n + 63) >> 6);
+  if (n_words < 0 || (size_t)n_words > nw) return fail(DQL_EINVAL, "n_words must be in 0 .. ceil(n_envs / 64)");
+  if (x->elog_n > max_periods || (x->elog_n && n_words && (!done_masks || !goal_masks))) return fail(DQL_EINVAL, "output buffers hold fewer periods than were logged");
+  HIP_TRY(hipSetDevice(x->device));
+  if (x->elog_n && n_words) {
+    const size_t k = (size_t)n_words, rows = (size_t)x->elog_n * 2;  // device rows: [period][done | goal][nw]
+    std::vector<unsigned long long> h(rows * k);
+    HIP_TRY(hipMemcpy2DAsync(h.data(), k * sizeof(unsigned long long), x->elog, nw * sizeof(unsigned long long), k * sizeof(unsigned long long), rows, hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    for (int p = 0; p < x->elog_n; ++p) {
+      memcpy(done_masks + (size_t)p * k, &h[(size_t)p * 2 * k], k * sizeof(uint64_t));
+      memcpy(goal_masks + (size_t)p * k, &h[(size_t)p * 2 * k + k], k * sizeof(uint64_t));
+    }
+  }
+  *n_periods = x->elog_n;
+  x->elog_n = 0;
+  return DQL_OK;
+}
+
 // ---- stateless operators ----
 struct DevBuf {
   void* p = nullptr;

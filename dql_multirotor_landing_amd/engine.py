@@ -299,13 +299,19 @@ class Engine:
         _lib.check(self.lib.dql_episode_log_enable(self._h, int(capacity_periods)))
         self._elog_cap = int(capacity_periods)
 
-    def episode_log_read(self):
-        """(done, goal) uint64[n_periods, n_waves]: bit l of word w = env 64 w + l finished an episode / finished it in the goal state"""
+    def episode_log_read(self, words=None):
+        """(done, goal) uint64[n_periods, n_waves]: bit l of word w = env 64 w + l finished an episode / finished it in the goal state.
+        words = k: only the first k words of every period (the first 64 k envs) cross the bus — what a caller judging a few envs needs."""
         nw = (self.n + 63) // 64
+        if words is not None:
+            nw = max(0, min(int(words), nw))
         done = np.zeros((self._elog_cap, nw), dtype=np.uint64)
         goal = np.zeros((self._elog_cap, nw), dtype=np.uint64)
         k = C.c_int32()
-        _lib.check(self.lib.dql_episode_log_read(self._h, _p(done), _p(goal), self._elog_cap, C.byref(k)))
+        if words is None:
+            _lib.check(self.lib.dql_episode_log_read(self._h, _p(done), _p(goal), self._elog_cap, C.byref(k)))
+        else:
+            _lib.check(self.lib.dql_episode_log_read_words(self._h, _p(done), _p(goal), self._elog_cap, nw, C.byref(k)))
         return done[:k.value], goal[:k.value]
 
     def state_bytes_per_env(self) -> int:

@@ -399,6 +399,11 @@ class Trainer:
             eng.episode_log_enable(self._chunk_steps)
         pw = PromotionWindow(self._successive_successful_episodes, self._success_rate)
         j_cnt, j_w, j_valid = self._judge_layout()
+        # only the judged envs' words of the log cross the bus when the engine can restrict the read (16 B per env and chunk otherwise)
+        import inspect
+        read_log = getattr(eng, "episode_log_read", None)  # (only the ordered rule reads the log)
+        if read_log is not None and "words" in inspect.signature(read_log).parameters:
+            read_log = lambda: eng.episode_log_read(words=(j_cnt + 63) // 64)
         order = EpisodeOrder(j_valid.size, j_valid)
         first_level = self._working_curriculum_step
         for self._working_curriculum_step in range(self._working_curriculum_step, self._curriculum_steps):
@@ -442,7 +447,7 @@ class Trainer:
                 s_prev = s
                 hit = None
                 if ordered:
-                    done, goal = self._judge_masks(*eng.episode_log_read(), j_cnt, j_w)
+                    done, goal = self._judge_masks(*read_log(), j_cnt, j_w)
                     hit = pw.push_flags(order.push(done, goal))
                 episodes += new_eps
                 self._current_episode = episodes

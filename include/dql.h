@@ -315,6 +315,9 @@ int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 int dql_episode_log_enable(dql_ctx* ctx, int32_t capacity_periods); /* 0 disables and frees */
 /* copies the periods logged since the last read into done_masks / goal_masks [n_periods][n_waves] and empties the log */
 int dql_episode_log_read(dql_ctx* ctx, uint64_t* done_masks, uint64_t* goal_masks, int32_t max_periods, int32_t* n_periods);
+/* the same, restricted to the first n_words words (64 envs each) of every period: done_masks / goal_masks [n_periods][n_words].  The
+ * promotion rule (pkg/trainer.py:218-232) judges a fixed few envs — the first global env ids —, the population's totals come from dql_stats_get. */
+int dql_episode_log_read_words(dql_ctx* ctx, uint64_t* done_masks, uint64_t* goal_masks, int32_t max_periods, int32_t n_words, int32_t* n_periods);
 
 /* ---- stateless batch operators (host arrays in/out, computed on the device; drop-in class methods) ---- */
 /* TrainingMdp.discrete_state (pkg/mdp.py:257-333): 4 x double[n] -> packed idx int32[n]; -1 where the reference raises */

@@ -617,6 +617,21 @@ def test_episode_log_matches_oracle(mods, n, block):
     with pytest.raises(ValueError):
         eng.train_steps(1, 0.2)  # DQL_ESTATE: log full
     eng.episode_log_read()
+    # restricted read (dql_episode_log_read_words): the first k words of every period, same bits, log emptied all the same
+    twin = Engine(DqlConfig(**cfg), n, seed=11)
+    if block:
+        twin.set_option("block", block)
+    twin.episode_log_enable(40)
+    for eps in (1.0, 0.2, 0.2, 0.2):  # the same launches eng has made so far
+        twin.train_steps(40, eps); twin.episode_log_read(words=0)
+    for k in (1, 3, 0, 10**6):
+        eng.train_steps(40, 0.2); twin.train_steps(40, 0.2)
+        df, gf = eng.episode_log_read()
+        dk, gk = twin.episode_log_read(words=k)
+        kk = min(k, (n + 63) // 64)
+        assert dk.shape == (40, kk) and np.array_equal(dk, df[:, :kk]) and np.array_equal(gk, gf[:, :kk])
+        assert twin.episode_log_read()[0].shape[0] == 0
+    twin.close()
     eng.episode_log_enable(0)
     eng.train_steps(3, 0.2)
 
