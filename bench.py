@@ -40,10 +40,10 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 # algorithmic bytes per env-step = persistent per-env state words x 4 B, read once + written once per agent step
 ALGO_BYTES = {"x": 320, "x_per_env_platform": 328, "two_axis": 400}
 PRESETS = {
-    1: dict(envs=4096, two_axis=0, randomize_platform=0, noise=0, tag="configs[1]", what="4 096 vectorised envs, x-axis MDP, curriculum step 0, shared rpm platform r = 2 m, omega = 0.8 rad/s"),
-    2: dict(envs=65536, two_axis=1, randomize_platform=0, noise=0, tag="configs[2]", what="65 536 envs, joint x + y 2-axis MDP, curriculum step 0"),
-    3: dict(envs=32768, two_axis=0, randomize_platform=0, noise=0, tag="configs[3] share", what="262 144 envs / 8 GPUs = 32 768 envs per GPU, x-axis MDP, shared rpm platform (the curriculum leg runs its full 0 -> 4 schedule)"),
-    4: dict(envs=131072, two_axis=0, randomize_platform=1, noise=1, tag="configs[4] share",
+    1: dict(envs=4096, two_axis=0, randomize_platform=0, noise=0, tag="configs[1]", short="4 096 envs, x-axis MDP, level 0, shared rpm platform", what="4 096 vectorised envs, x-axis MDP, curriculum step 0, shared rpm platform r = 2 m, omega = 0.8 rad/s"),
+    2: dict(envs=65536, two_axis=1, randomize_platform=0, noise=0, tag="configs[2]", short="65 536 envs, joint x + y 2-axis MDP, level 0", what="65 536 envs, joint x + y 2-axis MDP, curriculum step 0"),
+    3: dict(envs=32768, two_axis=0, randomize_platform=0, noise=0, tag="configs[3] share", short="32 768 envs per GPU (262 144 / 8), x-axis MDP, level 0, shared rpm platform", what="262 144 envs / 8 GPUs = 32 768 envs per GPU, x-axis MDP, shared rpm platform (the curriculum leg runs its full 0 -> 4 schedule)"),
+    4: dict(envs=131072, two_axis=0, randomize_platform=1, noise=1, tag="configs[4] share", short="131 072 envs per GPU (1 048 576 / 8), per-env sinusoidal platforms + obs noise, x-axis MDP, level 0, f32 / int32 index",
             what="1 048 576 envs / 8 GPUs = 131 072 envs per GPU, per-env randomised sinusoidal platforms (r_x ~ U(1,3) m, t_x ~ U(0.8,1.6) m/s) + observation noise "
                  "0.25 m / 0.1 m/s with Kalman R = 0.1^2, x-axis MDP, curriculum step 0, fp32 dynamics / int32 packed table index"),
 }
@@ -172,12 +172,13 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
         return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper-mode MDP, reference update rule (quirks 0x60), one learning-rate step per agent period (Trainer default)",
                 "workload": f"BASELINE configs[3]{' share' if world > 1 or args.curriculum_envs == 32768 else ''}: {args.curriculum_envs} envs per GPU, full curriculum 0 -> 4",
                 "envs_per_gpu": args.curriculum_envs, "global_envs": n_global, "episode_budget_per_level": budget, "sync_period": CURRICULUM_SYNC, "trainer_kw": CURRICULUM_KW,
-                "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
+                "seeds": [r["seed"] for r in runs], "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
                 "level0_promoted_per_seed": [bool(r["levels"][0]["promoted"]) for r in runs],
                 "population_success_at_promotion": {"min": min(pops) if pops else None, "mean": sum(pops) / len(pops) if pops else None,
                                                     "note": "success rate of ALL envs' episodes over the chunks holding the most recent >= 100 episodes when the judged envs' deque passed 0.96 / 100"},
                 "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
+                                                "trained_worst_seed": {k: min(r["stage4_greedy_4096_episodes"][k] for r in runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},
                 "runs": runs}
     except Exception as e:  # noqa: BLE001 - the throughput line must survive
@@ -185,7 +186,7 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
         return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]} if rank == 0 else None
 
 
-def spawn_ranks(args) -> int:
+def spawn_ranks(args, child_argv=None) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU; this parent never
     touches the GPU), relay rank 0's JSON line, fail loudly when a rank cannot get its GPU or dies."""
     import socket
@@ -196,11 +197,12 @@ def spawn_ranks(args) -> int:
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     n = args.gpus
     procs, out0 = [], tempfile.TemporaryFile(mode="w+")
+    errs = [sys.stderr] + [tempfile.TemporaryFile(mode="w+") for _ in range(1, n)]  # ranks != 0 are heard only when the job fails
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
-                                      stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+        procs.append(subprocess.Popen(child_argv or [sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=out0 if r == 0 else errs[r], stderr=errs[r]))
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
@@ -219,6 +221,11 @@ def spawn_ranks(args) -> int:
                 p.wait(timeout=15)
             except subprocess.TimeoutExpired:
                 p.kill()
+        for r in range(1, n):
+            errs[r].seek(0)
+            tail = errs[r].read()[-2000:]
+            if tail.strip():
+                print(f"--- rank {r} ---\n{tail}", file=sys.stderr)
         print(f"bench.py: rank {failed[0]} of {n} exited with code {failed[1]}: fewer than {n} ranks ran, no result (needs {n} GPUs, one per rank)", file=sys.stderr)
         return 1
     out0.seek(0)
@@ -281,10 +288,82 @@ def single_gpu_block(tag, what, envs, two_axis, randomize_platform, noise, dtype
     out = {"workload": f"{tag}: {what}", "envs": envs, "value": dec / wall, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
            "device_ms_per_step": dev_ms / steps, "periods_per_launch": P,
            "roofline": roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec / n_launch, n_launch)}
-    v = valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, steps / n_launch)
+    v = valu_issue(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, steps / n_launch)
     if v:
-        out["valu_roofline"] = v
+        out["valu_issue"] = v
     return out
+
+
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 6000  # bytes: the driver keeps the last 8 KB of stdout; round 3's 26 KB line was cut and did not parse
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE line bench.py prints: the contract's keys + roofline + cpu_baseline + the headline figures of every leg, <= LINE_LIMIT bytes
+    whatever the number of curriculum seeds or ranks.  Everything else (per-seed runs, per-level records, notes, sources, the other sync
+    periods) goes to DETAIL_FILE next to this script, which the line names."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "preroll_steps", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "baseline_config", "envs_per_gpu", "global_envs", "sync_period", "periods_per_launch", "parallelism", "exchange_rehearsal",
+                                "algorithmic_bytes_per_env_step", "library_source_sha16"))
+    out["config"]["workload"] = str(cfg.get("workload", ""))[:160]
+    if not out["config"].get("exchange_rehearsal"):
+        out["config"].pop("exchange_rehearsal", None)
+    out["env_steps"] = full.get("env_steps")
+    roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "kernel_launches_timed", "agent_periods_per_launch",
+                 "algorithmic_bytes_per_env_step", "env_steps_per_launch")
+    out["roofline"] = _pick(full.get("roofline"), roof_keys)
+    issue_keys = ("valu_instr_per_env_wave_per_period", "env_waves_per_simd", "cycles_per_instr", "frac_at_2p4_ghz", "measured_clock_ghz", "frac_at_measured_clock")
+    if isinstance(full.get("valu_issue"), dict) and "frac_at_2p4_ghz" in full["valu_issue"]:
+        out["valu_issue"] = _pick(full["valu_issue"], issue_keys)
+    for blk in ("small_batch", "large_batch"):
+        b = full.get(blk)
+        if b:
+            out[blk] = {**_pick(b, ("envs", "value", "ms_per_step")), "roofline_frac": b["roofline"]["frac"], "kernel_avg_ms": b["roofline"]["kernel_avg_ms"],
+                        "traffic": b["roofline"].get("traffic")}
+            if isinstance(b.get("valu_issue"), dict) and "frac_at_2p4_ghz" in b["valu_issue"]:
+                out[blk]["valu_issue_frac_at_2p4_ghz"] = b["valu_issue"]["frac_at_2p4_ghz"]
+                out[blk]["valu_issue_frac_at_measured_clock"] = b["valu_issue"]["frac_at_measured_clock"]
+    if full.get("sync"):
+        out["sync"] = _pick(full["sync"], ("sync_period", "ms_per_step", "ms_per_step_no_exchange", "sync_ms_per_step", "exchange_device_ms", "exchanges_timed",
+                                           "staleness_bound_periods", "p2p_failed"))
+        out["sync_ms_per_step"] = full["sync"].get("sync_ms_per_step")
+    cur = full.get("curriculum")
+    if cur is not None:
+        if "error" in cur:
+            out["curriculum"] = {"error": str(cur["error"])[:300]}
+        else:
+            pop = cur.get("population_success_at_promotion") or {}
+            out["curriculum"] = {**_pick(cur, ("wall_to_stage4_s", "wall_all_levels_s", "envs_per_gpu", "global_envs", "sync_period", "seeds", "promoted_levels_per_seed")),
+                                 "population_success_at_promotion": _pick(pop, ("min", "mean")),
+                                 "stage4_greedy_4096_episodes": _pick(cur.get("stage4_greedy_4096_episodes"), ("trained_mean", "trained_worst_seed", "reference_assets"))}
+            out.update(_pick(full, ("promoted_levels", "goal_hold_rate", "touchdown_rate", "wall_to_stage4_s")))
+    if full.get("cpu_baseline"):
+        out["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value"))
+        out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", ""))[:200]
+    out["reference_quoted"] = _pick(full.get("reference_quoted"), ("reference+gazebo_env_steps_per_s", "realtime_ceiling", "reference_python_mdp+agent_steps_per_s"))
+    out["detail_file"] = DETAIL_FILE
+    # last resort, never expected: shed optional blocks rather than print a line the driver cannot parse
+    for k in ("reference_quoted", "large_batch", "small_batch", "valu_issue", "sync", "curriculum"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(full: dict) -> str:
+    """write the full record to DETAIL_FILE (next to this script; best effort) and return the compact line"""
+    try:
+        tmp = ROOT / (DETAIL_FILE + f".{os.getpid()}.tmp")
+        tmp.write_text(json.dumps(full, indent=1))
+        os.replace(tmp, ROOT / DETAIL_FILE)
+    except OSError as e:
+        print(f"bench.py: could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+    return json.dumps(compact_line(full))
 
 
 def main():
@@ -320,11 +399,14 @@ def main():
     ap.add_argument("--large-envs", type=int, default=1048576, help="secondary single-GPU block at a chip-filling batch (0 = skip)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
     ap.add_argument("--curriculum-envs", type=int, default=32768, help="envs per GPU of the curriculum leg (BASELINE configs[3]: 262 144 / 8)")
-    ap.add_argument("--curriculum-seeds", type=int, default=12, help="how many of the twelve seeds to run")
+    ap.add_argument("--curriculum-seeds", type=int, default=None,
+                    help="how many of the twelve seeds to run; default 12 on one GPU, 2 with several (the scaling sweep re-runs the leg at every N: its throughput leg is the same at N = 1 either way)")
     ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 384 per env")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.curriculum_seeds is None:
+        args.curriculum_seeds = 12 if args.gpus == 1 else 2
     pre = PRESETS[args.config]
     for k in ("envs", "two_axis", "randomize_platform", "noise"):
         if getattr(args, k) is None:
@@ -463,7 +545,8 @@ def main():
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "preroll_steps": args.preroll, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{tag}: " + (pre["what"] if not custom else f"{args.envs} envs per GPU, two_axis {args.two_axis}, per-env platform {args.randomize_platform}, noise {args.noise}") +
+            "config": {"workload": f"{tag}: " + (pre["short"] if not custom else f"{args.envs} envs per GPU, two_axis {args.two_axis}, per-env platform {args.randomize_platform}, noise {args.noise}"),
+                       "workload_long": f"{tag}: " + (pre["what"] if not custom else f"{args.envs} envs per GPU, two_axis {args.two_axis}, per-env platform {args.randomize_platform}, noise {args.noise}") +
                                    f"; eps {args.eps}, ONE fused kernel per {P} agent period(s) (env steps + table fold in writer workgroups), int64 LDS/global accumulators",
                        "baseline_config": args.config, "envs_per_gpu": args.envs, "global_envs": args.envs * world, "sync_period": args.sync_period if multi else 1,
                        "exchange_rehearsal": bool(args.exchange_rehearsal), "periods_per_launch": P, "fold_per_step": 1,
@@ -479,9 +562,9 @@ def main():
         if sync_info:
             out["sync"] = sync_info
             out["sync_ms_per_step"] = sync_info["sync_ms_per_step"]
-        valu = valu_roofline(args.envs, P, args.two_axis, args.randomize_platform, args.noise, args.dtype, k_ms, args.steps / n_launch if not multi else P)
+        valu = valu_issue(args.envs, P, args.two_axis, args.randomize_platform, args.noise, args.dtype, k_ms, args.steps / n_launch if not multi else P)
         if valu:
-            out["valu_roofline"] = valu
+            out["valu_issue"] = valu
         if not multi:
             # secondary single-GPU blocks, each with its own roofline from stream events of THIS run
             if args.small_envs > 0 and not (args.envs == args.small_envs and not custom and args.config == 1):
@@ -499,25 +582,37 @@ def main():
                 out["wall_to_stage4_s"] = curriculum["wall_to_stage4_s"]
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(min(args.envs, 4096), args.cpu_steps, dtype, {k: v for k, v in cfg_kw.items()})
-        print(json.dumps(out), flush=True)
+        print(emit(out), flush=True)
     if comm:
         comm.barrier()
         comm.close()
 
 
-def valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, periods_per_launch_avg):
-    """The roof that actually binds: wave64 VALU instructions through 1024 SIMDs, with the instruction count per env wave from the
-    committed PMC pass of THIS library's sources (profiles/r*_pmc_sq_summary.json, stamped) and issue costs per instruction FORM from the
-    asm micro benchmarks (tools/micro/pk_variants.hip, valu_forms.hip -> profiles/r2_pk_variants.jsonl, r2_valu_forms.jsonl; placement
-    verified from HW_ID).  What those found on this chip (2.3-2.4 GHz shader clock):
-      >= 2 waves per SIMD:  v_fma / v_mul / v_add / v_mov / v_and with VGPR or literal sources 0.95-1.25 ns (the guide's "2 cycles" row,
-                            2.3-3 cycles measured); ANY SGPR source operand 1.8-1.95 ns; compares, selects, min / max / med3, conversions,
-                            integer ops 1.7-1.9 ns (4 cycles); v_pk_*_f32 1.9-2.1 ns (two operations: no gain); v_sqrt / v_rcp 3.5 ns
-      one wave per SIMD:    every form 1.85-2.45 ns (the wave's own issue interval), v_pk_*_f32 2.4-2.6 ns (two operations: the gain the
-                            packed tick of small batches lives on), v_sqrt / v_rcp 3.6-3.9 ns
-    Three prices per launch: every instruction at the full-rate form's cost ("all_full_rate": no kernel with compares and selects can
-    reach it), the kernel's own mix of forms in the tick loop (tools/isa_sections.py, "own_mix"), and MI355X_MICROARCH.md's table row."""
-    if two_axis or dtype_name != "f32":
+def committed_clock(envs: int, cfg4: bool):
+    """shader clock measured INSIDE the step kernel at this batch size (tools/exp_phase_clock.py, diagnostic build: s_memtime cycles of a
+    launch / its HIP-event duration), newest committed profiles/r*_phase_clock.jsonl; (GHz, file) or (None, why)"""
+    for f in sorted((ROOT / "profiles").glob("r*_phase_clock.jsonl"), reverse=True):
+        rows = []
+        for ln in f.read_text().splitlines():
+            try:
+                rows.append(json.loads(ln))
+            except ValueError:
+                pass
+        rows = [r for r in rows if r.get("envs") == envs and 0.5 < r.get("implied_clock_ghz", 0) <= 2.6]  # (an oversubscribed batch's waves do not all run at once: no clock)
+        rows.sort(key=lambda r: (r.get("flavour") == "cfg4") == cfg4, reverse=True)
+        if rows:
+            return rows[0]["implied_clock_ghz"], f.name
+    return None, "no committed profiles/r*_phase_clock.jsonl row for this batch size"
+
+
+def valu_issue(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, periods_per_launch_avg):
+    """The roof that binds the fused step: wave64 VALU issue.  ONE price, MI355X_MICROARCH.md's table row (v_fma_f32 wave64: 2 cycles per
+    instruction per SIMD; a wave alone on its SIMD: 4), applied to the instruction count per env wave of the committed PMC pass of THIS
+    library's sources (profiles/r*_pmc_sq_summary.json, stamped):
+        valu_issue_frac = instructions per SIMD per launch x cycles / (kernel time x clock)
+    at the guide's 2.4 GHz and at the clock measured inside the kernel for this batch size (the chip sustains 1.9-2.0 GHz under a dense VALU
+    stream).  A fraction of what the SIMDs could issue: never above 1."""
+    if two_axis or dtype_name != "f32" or not k_ms or k_ms <= 0:
         return None
     pm, src = committed_profile("pmc_sq_summary")
     if pm is None:
@@ -530,25 +625,16 @@ def valu_roofline(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms
         if not same:
             return {"note": f"profiles/{src} has no pass of configuration {key}"}
         key = same[0]
-    ref = passes[key]
-    valu_per_wave = ref["SQ_INSTS_VALU_per_env_wave_per_period"] * periods_per_launch_avg  # per (average) launch of the timed region
+    per_period = passes[key]["SQ_INSTS_VALU_per_env_wave_per_period"]
     waves = (envs + 63) // 64
     lone = waves <= 1024
-    out = {"valu_instr_per_env_wave_per_launch": valu_per_wave, "valu_instr_per_env_wave_per_period": ref["SQ_INSTS_VALU_per_env_wave_per_period"],
-           "simds": 1024, "env_waves": waves, "regime": "one wave per SIMD" if lone else ">= 2 waves per SIMD",
-           "source": f"profiles/{src} [{key}] (instruction count, same kernel sources), profiles/r2_pk_variants.jsonl + r2_valu_forms.jsonl (issue cost per form)"}
-    # own mix per tick (tools/isa_sections.py x the table above): literal-constant loop (> 65 536 envs with the reference vehicle, which is what
-    # bench.py flies) 1.27 ns at round 2's instruction mix — round 3's tick has fewer four-cycle forms (sqrt_pos), so this floor is a little
-    # high and the fraction a little flattering; packed lone wave 2.3 ns.  profiles/r3_valu_forms_clock.jsonl gives the same costs in CYCLES
-    # with the in-kernel clock (1.86-1.97 GHz under a dense full-rate stream at >= 2 waves, 2.25-2.4 GHz otherwise)
-    mix = 2.3 if lone else 1.27
-    prices = (("all_full_rate", 2.2 if lone else 1.15), ("own_mix", mix), ("guide_table", (4 if lone else 2) / 2.4))
-    for tag, ns in prices:
-        floor_s = valu_per_wave * ns * 1e-9 * max(1.0, waves / 1024.0)
-        out[tag] = {"ns_per_wave64_valu_instr_per_simd": ns, "floor_ms_per_launch": floor_s * 1e3, "frac": floor_s * 1e3 / k_ms if k_ms > 0 else None}
-    out["note"] = ("informational: the fused step is bound by VALU issue (one wave's own instruction stream at small batches, all SIMDs busy at large ones), "
-                   "not by HBM; frac = floor / measured launch time")
-    return out
+    cycles = 4 if lone else 2
+    instr_per_simd = per_period * periods_per_launch_avg * max(1.0, waves / 1024.0)
+    clock, clock_src = committed_clock(envs, bool(randomize_platform and noise))
+    frac = lambda ghz: instr_per_simd * cycles / (k_ms * 1e-3 * ghz * 1e9)
+    return {"valu_instr_per_env_wave_per_period": per_period, "env_waves_per_simd": waves / 1024.0, "cycles_per_instr": cycles,
+            "frac_at_2p4_ghz": frac(2.4), "measured_clock_ghz": clock, "frac_at_measured_clock": frac(clock) if clock else None,
+            "source": f"profiles/{src} [{key}]" + (f", profiles/{clock_src}" if clock else f"; {clock_src}")}
 
 
 if __name__ == "__main__":
