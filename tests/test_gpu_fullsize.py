@@ -9,7 +9,7 @@ run a million envs in seconds, so here the product is checked against itself and
 import numpy as np
 import pytest
 
-from dql_multirotor_landing_amd.config import DqlConfig, F32
+from dql_multirotor_landing_amd.config import DqlConfig, F32, Q_PAPER
 
 pytestmark = pytest.mark.gpu
 
@@ -137,3 +137,35 @@ def test_config5_flags_at_131072_envs(Engine):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("extra", [{}, dict(quirks=Q_PAPER, fold_per_step=1)])
+def test_headline_instance_training_slice_equals_oracle(Engine, extra):
+    """The instance the default bench flies — 131 072 envs with the configs[4] flags, automatic choice of workgroup and tick layout
+    (`k_step<float,256,LIT>`), 16 agent periods per launch, TRAIN mode (eps-greedy actions, TD targets, table folds) — against the oracle:
+    a 192-env slice of the run on the same global env ids is handed, launch by launch, the acting tables of the big run (its master tables as
+    they were two launches earlier: the fold acts with one launch of delay) and must end in the same bits.  Reference update rule, and the
+    Trainer's (Double Q-learning in paper mode, one learning-rate step per period)."""
+    from oracle.oracle import Oracle
+    kw = dict(dtype=F32, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, t_max=6.0, **extra)
+    n, P, launches, eps = 131072, 16, 4, 0.4
+    lo, m = 100_000, 192
+    ref = Engine(DqlConfig(**kw), n, seed=4242)
+    ref.set_option("periods_per_launch", P)
+    orc = Oracle(DqlConfig(**kw), m, seed=4242, env_id_offset=lo, n_threads=4)
+    orc.set_option("periods_per_launch", P)
+    t0 = ref.get_tables()
+    masters = [(t0[0].ravel().copy(), t0[1].ravel().copy())] * 2  # masters[-2] = acting tables of the next launch
+    for _ in range(launches):
+        orc.qa_act[:] = masters[-2][0]; orc.qb_act[:] = masters[-2][1]
+        ref.train_steps(P, eps)
+        t = ref.get_tables()
+        masters.append((t[0].ravel().copy(), t[1].ravel().copy()))
+        orc._period(0, eps, n_periods=P); orc.pending = None
+    reals, ints = ref.get_fields()
+    o_r, o_i = orc.get_fields()
+    np.testing.assert_array_equal(ints[:, lo:lo + m], o_i)
+    np.testing.assert_array_equal(reals[:, lo:lo + m], o_r)
+    st = ref.stats()
+    assert st["episodes"] > n // 2 and masters[-1][0].any() and (not extra or masters[-1][1].any())
+    ref.close()

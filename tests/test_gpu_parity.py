@@ -662,17 +662,22 @@ def test_double_q_learning_updates_both_tables_in_paper_mode(mods):
 
 @pytest.mark.parametrize("tick,block,kw", [(1, 0, {}), (2, 0, {}), (2, 256, {}), (3, 64, {}), (3, 256, {}), (4, 0, {}), (4, 64, {}), (4, 512, {}), (1, 512, {}),
                                            (0, 512, dict(two_axis=1, trajectory=TRAJ_EIGHT)), (4, 512, dict(vz_setpoint=-0.4, working_curriculum_step=3, init_uniform=1)),
-                                           (3, 0, dict(two_axis=1, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1))])
+                                           (3, 0, dict(two_axis=1, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1)),
+                                           # the bench's headline instance k_step<float,256,LIT> in TRAIN mode, 16 periods per launch: plain, and with the configs[4] flags + the Trainer's update rule
+                                           (4, 256, dict(ppl=16)),
+                                           (4, 256, dict(ppl=16, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, quirks=Q_PAPER, fold_per_step=1))])
 def test_tick_layouts_bit_exact(mods, tick, block, kw):
     """Options "tick" / "block": every layout of the 500 Hz loop (plain, VGPR constants, packed float32, literal constants) and every
     workgroup size (64 .. 512 threads, the last with the register budget of 4 waves per SIMD: cold values in scratch) computes the
     same bits as the oracle.  n spans full and ragged workgroups; 3 periods per launch; episodes end inside launches."""
     Engine, Oracle = mods
     n = 1100
+    kw = dict(kw)
+    ppl = kw.pop("ppl", 3)
     cfg = dict(dtype=F32, t_max=4.0, **kw)
     eng = Engine(DqlConfig(**cfg), n, seed=21); orc = Oracle(DqlConfig(**cfg), n, seed=21, n_threads=8)
     eng.set_option("tick", tick); eng.set_option("block", block)
-    eng.set_option("periods_per_launch", 3); orc.set_option("periods_per_launch", 3)
+    eng.set_option("periods_per_launch", ppl); orc.set_option("periods_per_launch", ppl)
     g = Path(__file__).parent / "golden" / "assets"
     qa, qb, cnt = (np.load(g / f) for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"))
     eng.set_tables(qa, qb, cnt); orc.set_tables(qa, qb, cnt)
