@@ -187,13 +187,13 @@ def test_g14_discriminates_the_launch_files_literal_values():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [F32, F64])
 def test_g14_random_policy_statistics_hip(dtype):
-    """the product path through the C ABI: 8 192 envs, >= 10^5 episodes, the dtype every throughput figure is measured in and float64"""
+    """the product path through the C ABI: 16 384 envs, >= 10^5 episodes, the dtype every throughput figure is measured in and float64"""
     from dql_multirotor_landing_amd.engine import Engine
 
     def make(cfg, n):
         return Engine(cfg, n, seed=42)
 
-    code, steps, cum = fly_random_policy(make, as_launched_config(dtype=dtype), 8192, 1200, read_engine)
+    code, steps, cum = fly_random_policy(make, as_launched_config(dtype=dtype), 16384, 1500, read_engine)
     assert len(code) >= 100000
     res = compare_with_gazebo(code, steps, cum)
     print(_report(res))
