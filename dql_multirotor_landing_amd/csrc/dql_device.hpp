@@ -228,6 +228,7 @@ template <typename T> struct MdpK {
   T p_max, v_max, a_max, theta_max, delta_theta, beta, sigma_a, min_alt;
   T w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   T lim_p[5], lim_v[5], lim_a[5], angles[7];
+  T inv_p_max, inv_v_max, inv_a_max, inv_theta_max, dtheta_ratio;  // float32 MDP (round 4): reciprocals of the normalising constants, delta_theta / theta_max
   double gamma;
   int working, goal_logic;
   uint32_t quirks;
@@ -241,6 +242,7 @@ template <typename T> struct SimK {
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
   T bw_k1, bw_k2, bw_inv;
+  T bw_b2, bw_a2, bw_a3;  // float32 tick (round 4): transposed Butterworth, 2 / denom, k2 / denom, k1 / denom
   T mp_dt, mp_top, mp_hx, mp_hy, bottom;
   T noise_p, noise_v, kal_q, kal_r, mgr_dt, mp_r, mp_w;
   T p_max, theta_max, delta_theta, z_init, init_sigma;  // reset placement / set-point update (before the loop)
@@ -258,7 +260,7 @@ template <typename T> struct HotK {
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
-  T bw_k1, bw_k2, bw_inv;
+  T bw_k1, bw_k2, bw_inv, bw_b2, bw_a2, bw_a3;
   T mp_top, mp_hx, mp_hy, bottom;
 };
 DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
@@ -270,7 +272,7 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   DQL_HOT(kR[0]); DQL_HOT(kR[1]); DQL_HOT(kR[2]); DQL_HOT(kW[0]); DQL_HOT(kW[1]); DQL_HOT(kW[2]); DQL_HOT(ia); DQL_HOT(ib); DQL_HOT(ic);
   DQL_HOT(vz_kp); DQL_HOT(vz_ki); DQL_HOT(vz_lo); DQL_HOT(vz_hi); DQL_HOT(vz_wind); DQL_HOT(vz_sp);
   DQL_HOT(yw_kp); DQL_HOT(yw_ki); DQL_HOT(yw_lo); DQL_HOT(yw_hi); DQL_HOT(yw_wind); DQL_HOT(yw_sp);
-  DQL_HOT(bw_k1); DQL_HOT(bw_inv); DQL_HOT(mp_top); DQL_HOT(mp_hx); DQL_HOT(mp_hy); DQL_HOT(bottom);
+  DQL_HOT(bw_k1); DQL_HOT(bw_inv); DQL_HOT(bw_b2); DQL_HOT(bw_a2); DQL_HOT(bw_a3); DQL_HOT(mp_top); DQL_HOT(mp_hx); DQL_HOT(mp_hy); DQL_HOT(bottom);
 #undef DQL_HOT
   h.bw_k2 = s.bw_k2;  // only steers a wave-uniform branch
   return h;
@@ -335,10 +337,16 @@ template <typename T> DQL_DEV int disc3(T v, T goal, T limit) {  // :160-170
   if (v <= limit) return 2;
   return -1;
 }
+// FLOAT32 MDP, ROUND 4: the normalising divisions by the constants p_max, v_max, a_max, theta_max are multiplications by the host's reciprocals
+// (a correctly rounded float32 division is ~10 instructions, seven of them per agent period); float64 keeps the reference's divisions (G1 / G2)
+template <typename T> DQL_DEV T norm_by(T x, T d, T inv) {
+  if constexpr (sizeof(T) == 4) return x * inv;
+  else return x / d;
+}
 template <typename T> DQL_DEV int discretise(const MdpK<T>& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
-  const T cp = clip(rel_p / m.p_max, T(-1.0), T(1.0));
-  const T cv = clip(rel_v / m.v_max, T(-1.0), T(1.0));
-  const T ca = clip(rel_a / m.a_max, T(-1.0), T(1.0));
+  const T cp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
+  const T cv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
+  const T ca = clip(norm_by(rel_a, m.a_max, m.inv_a_max), T(-1.0), T(1.0));
   const int n = m.working + 1;
   int k = latest_valid_level(m.lim_p, n, cp);
   const int kv = latest_valid_level(m.lim_v, n, cv), ka = latest_valid_level(m.lim_a, n, ca);
@@ -397,21 +405,23 @@ DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int cod
 }
 template <typename T>
 DQL_DEV T mdp_reward(const MdpK<T>& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
-  const T ncp = clip(rel_p / m.p_max, T(-1.0), T(1.0));
-  const T ncv = clip(rel_v / m.v_max, T(-1.0), T(1.0));
-  const T npitch = angle_sp / m.theta_max;
+  const T ncp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
+  const T ncv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
+  const T npitch = norm_by(angle_sp, m.theta_max, m.inv_theta_max);
   const int k = idx_level(cur_idx);
   const T lv = sel5(m.lim_v, k), la = sel5(m.lim_a, k);
   const T prev_p = shp_p, prev_v = shp_v, prev_a = shp_a;
   shp_p = m.w_p * abs_(ncp); shp_v = m.w_v * abs_(ncv); shp_a = m.w_theta * abs_(npitch);
   const T r_p_max = abs_(m.w_p) * lv * m.delta_t;
   const T r_v_max = abs_(m.w_v) * la * m.delta_t;
-  const T r_theta_max = abs_(m.w_theta) * (m.delta_theta / m.theta_max) * lv;
+  T r_theta_max;
+  if constexpr (sizeof(T) == 4) r_theta_max = abs_(m.w_theta) * m.dtheta_ratio * lv;
+  else r_theta_max = abs_(m.w_theta) * (m.delta_theta / m.theta_max) * lv;
   const T r_dur_max = m.w_dur * lv * m.delta_t;
   const T r_max = r_p_max + r_v_max + r_theta_max + r_dur_max;
   const T r_p = clip(shp_p - prev_p, -r_p_max, r_p_max);
   const T r_v = clip(shp_v - prev_v, -r_v_max, r_v_max);
-  const T r_theta = m.w_theta * (abs_(shp_a) - abs_(prev_a)) / m.theta_max * lv;
+  const T r_theta = norm_by(m.w_theta * (abs_(shp_a) - abs_(prev_a)), m.theta_max, m.inv_theta_max) * lv;
   const T r_dur = m.w_dur * lv * m.delta_t;
   T r_term;
   if (code == DQL_NON_TERMINAL_SUCCESS || code == DQL_TERMINAL_SUCCESS) r_term = m.w_succ * r_max;
@@ -448,10 +458,41 @@ template <typename TabPtr> DQL_DEV int agent_predict(TabPtr qa, TabPtr qb, int i
 // build (oracle/dql_oracle.c, ORACLE_F32) spells out the same sequence, so float32 parity stays bit for bit; float32 against float64 stays
 // within the north_star tolerance (tests/test_gpu_parity.py::test_f32_kernel_vs_f64_oracle_one_period).
 template <typename T> struct Fast32 { static constexpr bool on = sizeof(T) == 4; };
+// x * k + y with the result in a register of its OWN choosing (VOP3 v_fma_f32 / v_fmamk_f32 with a literal), k = a member of the tick constants
+// picked by a tag: the constant is a literal (LitK), a VGPR (HotK) or an SGPR (SimK) depending on the layout
+struct BwInv { template <typename K> static DQL_DEV constexpr auto get(const K& c) { return c.bw_inv; } };
+struct BwB2 { template <typename K> static DQL_DEV constexpr auto get(const K& c) { return c.bw_b2; } };
+struct LitK;
+template <typename T> struct HotK;
+template <typename Tag, typename K> DQL_DEV float fma3(const K& c, float x, float y) {
+  float d;
+  if constexpr (__is_same(K, LitK)) {
+    constexpr float k = Tag::get(K{});
+    asm("v_fmamk_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(__builtin_bit_cast(int, k)), "v"(y));
+  } else if constexpr (__is_same(K, HotK<float>)) {
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(Tag::get(c)), "v"(y));
+  } else {
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"((float)Tag::get(c)), "v"(y));
+  }
+  return d;
+}
+template <typename Tag, typename K> DQL_DEV double fma3(const K& c, double x, double y) { return fma_((double)Tag::get(c), x, y); }
 template <typename T, typename K> DQL_DEV T butterworth(const K& c, T x0, T& x1, T& x2, T& y1, T& y2, T& y3) {  // filters.py:98-109
-  T acc;
-  if constexpr (Fast32<T>::on) acc = fma_(-T(c.bw_k1), y3, fma_(T(2.0), x1, x2) + x0);
-  else acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
+  if constexpr (Fast32<T>::on) {
+    // ROUND 4: the reference's recurrence y[n] = b (x[n] + 2 x[n-1] + x[n-2]) - a2 y[n-2] - a3 y[n-3] as a TRANSPOSED direct form:
+    //   y = b x + t1;  t1 = 2b x + t2;  t2 = b x - a2 y + t3;  t3 = -a3 y
+    // three states (kept in the fields x1, x2, y1; y2, y3 unused) instead of five histories, and no history shifts: the rolled tick loop paid ten
+    // v_mov per tick for them.  4 instructions per filter instead of 4 + 5.
+    // fma3: three-address fmas.  The compiler's two-address v_fmac ties a result to its addend's register, which here rotates the three states
+    // by one register per tick — and the rolled loop then pays three v_mov per filter to rotate them back.
+    const T value = fma3<BwInv>(c, x0, x1);
+    x1 = fma3<BwB2>(c, x0, x2);
+    x2 = fma3<BwInv>(c, x0, y1);
+    if (c.bw_k2 != 0) x2 = fma_(-T(c.bw_a2), value, x2);
+    y1 = -(T(c.bw_a3) * value);
+    return value;
+  }
+  T acc = x2 + T(2.0) * x1 + x0 - c.bw_k1 * y3;
   if (c.bw_k2 != 0) acc = acc - (c.bw_k2 * y2);  // -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106)
   const T value = c.bw_inv * acc;
   x2 = x1; x1 = x0;
@@ -486,6 +527,16 @@ template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z) {  // filte
 // ---------------------------------------------------------------------------------------------
 template <typename T> DQL_DEV void quat_to_R(const T (&q)[4], T (&R)[9]) {
   const T w = q[0], x = q[1], y = q[2], z = q[3];
+  if constexpr (Fast32<T>::on) {  // round 4: the factor 2 applied once to x, y, z (exact), every entry one or two fused multiply-adds: 17 instructions instead of 30
+    const T x2 = x + x, y2 = y + y, z2 = z + z;
+    const T t = fma_(-z, z2, T(1.0));
+    R[0] = fma_(-y, y2, t); R[4] = fma_(-x, x2, t); R[8] = fma_(-x, x2, fma_(-y, y2, T(1.0)));
+    const T wx2 = w * x2, wy2 = w * y2, wz2 = w * z2;
+    R[1] = fma_(x, y2, -wz2); R[3] = fma_(x, y2, wz2);
+    R[2] = fma_(x, z2, wy2); R[6] = fma_(x, z2, -wy2);
+    R[5] = fma_(y, z2, -wx2); R[7] = fma_(y, z2, wx2);
+    return;
+  }
   const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
   R[0] = T(1.0) - T(2.0) * (yy + zz); R[1] = T(2.0) * (xy - wz); R[2] = T(2.0) * (xz + wy);
   R[3] = T(2.0) * (xy + wz); R[4] = T(1.0) - T(2.0) * (xx + zz); R[5] = T(2.0) * (yz - wx);
@@ -497,7 +548,8 @@ template <typename T> DQL_DEV void quat_to_R(const T (&q)[4], T (&R)[9]) {
 template <typename T> struct YawIters;
 template <> struct YawIters<float> { static constexpr int n = 4; };
 template <> struct YawIters<double> { static constexpr int n = 5; };
-// float32 (FAST32): second-order start 1 + d/2 + 3 d^2 / 8, d = 1 - n2 (error 5 d^3 / 16), then TWO Newton steps: 2e-9 at a tilt of 30 deg
+// float32 (FAST32): second-order start 1 + d/2 + 3 d^2 / 8, d = 1 - n2 (error 5 d^3 / 16), then THREE Newton steps (round 4: two left 2e-5 at a tilt
+// of 45 deg and 0.5 % at 60 deg; three are converged to rounding up to 60 deg)
 template <typename T> DQL_DEV T yaw_rnorm(T n2) {
   const T h = T(-0.5) * n2;
   T r;
@@ -505,7 +557,7 @@ template <typename T> DQL_DEV T yaw_rnorm(T n2) {
     const T d = T(1.0) - n2;
     r = fma_(fma_(T(0.375), d, T(0.5)), d, T(1.0));
 #pragma unroll
-    for (int k = 0; k < 2; ++k) r = r * fma_(h * r, r, T(1.5));
+    for (int k = 0; k < 3; ++k) r = r * fma_(h * r, r, T(1.5));
   } else {
     r = fma_(T(-0.5), n2, T(1.5));
 #pragma unroll
@@ -548,17 +600,20 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
     E01 = DQL_E(0, 1); E10 = DQL_E(1, 0); E02 = DQL_E(0, 2); E20 = DQL_E(2, 0); E12 = DQL_E(1, 2); E21 = DQL_E(2, 1); E22 = DQL_E(2, 2);
 #undef DQL_E
   }
-  const T eR0 = T(0.5) * (E21 - E12), eR1 = T(0.5) * (E02 - E20), eR2 = T(0.5) * (E10 - E01);
   if constexpr (Fast32<T>::on) {
+    // e_R = (E_ji - E_ij) / 2 and M = -k_W e_W - k_R e_R: the halving is folded into the gain, (0.5 d) k == d (0.5 k) bit for bit (scaling by a
+    // power of two is exact), three multiplications fewer per tick and the same value — the oracle keeps the reference's order
+    const T dR0 = E21 - E12, dR1 = E02 - E20, dR2 = E10 - E01;
     const T eW0 = fma_(-r_cmd, E02, w[0]), eW1 = fma_(-r_cmd, E12, w[1]), eW2 = fma_(-r_cmd, E22, w[2]);
-    const T M0 = fma_(-eW0, T(s.kW[0]), -(eR0 * s.kR[0]));
-    const T M1 = fma_(-eW1, T(s.kW[1]), -(eR1 * s.kR[1]));
-    const T M2 = fma_(-eW2, T(s.kW[2]), -(eR2 * s.kR[2]));
+    const T M0 = fma_(-eW0, T(s.kW[0]), -(dR0 * (T(0.5) * T(s.kR[0]))));
+    const T M1 = fma_(-eW1, T(s.kW[1]), -(dR1 * (T(0.5) * T(s.kR[1]))));
+    const T M2 = fma_(-eW2, T(s.kW[2]), -(dR2 * (T(0.5) * T(s.kR[2]))));
     const T a = thrust * s.ia;
     const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
 #pragma unroll
     for (int i = 0; i < 4; ++i) cmd[i] = sqrt_pos(w2[i] > SQRT_POS_MIN ? w2[i] : SQRT_POS_MIN);  // a rotor commanded to stop is commanded to 1e-15 rad/s
   } else {
+    const T eR0 = T(0.5) * (E21 - E12), eR1 = T(0.5) * (E02 - E20), eR2 = T(0.5) * (E10 - E01);
     const T eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
     const T M0 = -(eR0 * s.kR[0]) - eW0 * s.kW[0];
     const T M1 = -(eR1 * s.kR[1]) - eW1 * s.kW[1];
@@ -615,7 +670,10 @@ template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e,
   const T Iw0 = s.I[0] * w0, Iw1 = s.I[1] * w1, Iw2 = s.I[2] * w2;
   const T g0 = fma_(w1, Iw2, -(w2 * Iw1)), g1 = fma_(w2, Iw0, -(w0 * Iw2)), g2 = fma_(w0, Iw1, -(w1 * Iw0));
   if constexpr (Fast32<T>::on) {
-    e.w[0] = fma_(T(s.dtI[0]), tx - g0, w0); e.w[1] = fma_(T(s.dtI[1]), ty - g1, w1); e.w[2] = fma_(T(s.dtI[2]), tz - g2, w2);
+    e.w[0] = fma_(T(s.dtI[0]), tx - g0, w0); e.w[1] = fma_(T(s.dtI[1]), ty - g1, w1);
+    // round 4: (w x I w)_z = (I_y - I_x) w_x w_y is exactly 0 for a vehicle with I_x = I_y (the reference's; wave-uniform / compile-time test)
+    if (T(s.I[0]) == T(s.I[1])) e.w[2] = fma_(T(s.dtI[2]), tz, w2);
+    else e.w[2] = fma_(T(s.dtI[2]), tz - g2, w2);
   } else {
     e.w[0] = fma_(s.dt, (tx - g0) * s.inv_I[0], w0);
     e.w[1] = fma_(s.dt, (ty - g1) * s.inv_I[1], w1);
@@ -701,7 +759,13 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
 // platform extrapolation between manager ticks + bumper contact test
 template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e) {
   e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
-  if (e.p[2] - s.bottom <= s.mp_top && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+  // the footprint test only where some lane of the wave is low enough to touch (a real branch: a training flight descends at 0.1 m/s from
+  // 4 m and ends after 20 s at the latest — it never gets there, and the tick pays two instructions instead of eight)
+  const bool low = e.p[2] - s.bottom <= s.mp_top;
+  if (__ballot(low) != 0ull) {
+    asm volatile("; footprint test" ::: "memory");  // keeps the block a block: the compiler otherwise flattens it into selects again
+    if (low && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+  }
 }
 // B = Rx(roll_sp) Ry(pitch_sp) (attitude_controller.py:138-140), constant over one agent period
 template <typename T> DQL_DEV void make_B(T pitch_sp, T roll_sp, T (&B)[9]) {
@@ -750,7 +814,7 @@ DQL_DEV f2 mk2(float a, float b) { return f2{opq(a), opq(b)}; }
 struct TickPk {
   f2 q_wx, q_yz, w01, v01, p01, om02, om13;
   float w2, v2, p2;
-  f2 pid_i, pid_x1, pid_x2, pid_y1, pid_y2, pid_y3, pid_state;  // (v_z controller, yaw controller)
+  f2 pid_i, pid_x1, pid_x2, pid_y1, pid_state;  // (v_z controller, yaw controller); x1, x2, y1 = the transposed Butterworth's t1, t2, t3
   f2 mp_xy, mp_uv;
 };
 struct RotPk { f2 R04, R13, R26, R57, R01, R34, R67; float R8, cy, sy, ct, rn; };  // rotation matrix: symmetric partners + row pairs; yaw frame
@@ -762,7 +826,7 @@ DQL_DEV void pack_tick(const Env<float>& e, TickPk& s) {
   s.p01 = mk2(e.p[0], e.p[1]); s.p2 = e.p[2];
   s.om02 = mk2(e.om[0], e.om[2]); s.om13 = mk2(e.om[1], e.om[3]);
   s.pid_i = mk2(e.vz_i, e.yw_i); s.pid_x1 = mk2(e.vz_x1, e.yw_x1); s.pid_x2 = mk2(e.vz_x2, e.yw_x2);
-  s.pid_y1 = mk2(e.vz_y1, e.yw_y1); s.pid_y2 = mk2(e.vz_y2, e.yw_y2); s.pid_y3 = mk2(e.vz_y3, e.yw_y3);
+  s.pid_y1 = mk2(e.vz_y1, e.yw_y1);
   s.pid_state = mk2(e.vz_state, e.yw_state);
   s.mp_xy = mk2(e.mp_x, e.mp_y); s.mp_uv = mk2(e.mp_u, e.mp_v);
 }
@@ -773,23 +837,25 @@ DQL_DEV void unpack_tick(const TickPk& s, Env<float>& e) {
   e.p[0] = opq(s.p01.x); e.p[1] = opq(s.p01.y); e.p[2] = s.p2;
   e.om[0] = opq(s.om02.x); e.om[2] = opq(s.om02.y); e.om[1] = opq(s.om13.x); e.om[3] = opq(s.om13.y);
   e.vz_i = opq(s.pid_i.x); e.yw_i = opq(s.pid_i.y); e.vz_x1 = opq(s.pid_x1.x); e.yw_x1 = opq(s.pid_x1.y); e.vz_x2 = opq(s.pid_x2.x); e.yw_x2 = opq(s.pid_x2.y);
-  e.vz_y1 = opq(s.pid_y1.x); e.yw_y1 = opq(s.pid_y1.y); e.vz_y2 = opq(s.pid_y2.x); e.yw_y2 = opq(s.pid_y2.y); e.vz_y3 = opq(s.pid_y3.x); e.yw_y3 = opq(s.pid_y3.y);
+  e.vz_y1 = opq(s.pid_y1.x); e.yw_y1 = opq(s.pid_y1.y);
   e.vz_state = opq(s.pid_state.x); e.yw_state = opq(s.pid_state.y);
   e.mp_x = opq(s.mp_xy.x); e.mp_y = opq(s.mp_xy.y); e.mp_u = opq(s.mp_uv.x); e.mp_v = opq(s.mp_uv.y);
 }
 // quat_to_R + yaw_cs
 DQL_DEV void rot_pk(const TickPk& s, RotPk& r) {
+  // quat_to_R's float32 form (round 4), component by component: doubled x, y, z, then one or two fmas per entry
   const f2 xy = f2{s.q_wx.y, s.q_yz.x};
-  const f2 sq = xy * xy;                                       // (xx, yy)
-  const f2 zz_xy = f2{s.q_yz.y, xy.x} * f2{s.q_yz.y, xy.y};    // (zz, xy)
-  const f2 xz_yz = xy * hi2(s.q_yz);                           // (xz, yz)
-  const f2 wx_wy = lo2(s.q_wx) * xy;                           // (wx, wy)
-  const float wz = s.q_wx.x * s.q_yz.y;
-  r.R04 = bc2(1.0f) - bc2(2.0f) * (swp2(sq) + lo2(zz_xy));     // R0 = 1 - 2 (yy + zz), R4 = 1 - 2 (xx + zz)
-  r.R8 = 1.0f - 2.0f * (sq.x + sq.y);
-  r.R13 = bc2(2.0f) * pfma(bc2(wz), f2{-1.0f, 1.0f}, hi2(zz_xy));       // 2 (xy - wz), 2 (xy + wz)
-  r.R26 = bc2(2.0f) * pfma(hi2(wx_wy), f2{1.0f, -1.0f}, lo2(xz_yz));    // 2 (xz + wy), 2 (xz - wy)
-  r.R57 = bc2(2.0f) * pfma(lo2(wx_wy), f2{-1.0f, 1.0f}, hi2(xz_yz));    // 2 (yz - wx), 2 (yz + wx)
+  const float w = s.q_wx.x, z = s.q_yz.y;
+  const f2 xy2 = xy + xy;                                                  // (x2, y2)
+  const float z2 = z + z;
+  const float t = fma_(-z, z2, 1.0f);
+  r.R04 = pfma(-swp2(xy), swp2(xy2), bc2(t));                              // R0 = fma(-y, y2, t), R4 = fma(-x, x2, t)
+  r.R8 = fma_(-xy.x, xy2.x, fma_(-xy.y, xy2.y, 1.0f));
+  const f2 wxy2 = bc2(w) * xy2;                                            // (w x2, w y2)
+  const float wz2 = w * z2;
+  r.R13 = pfma(lo2(xy), hi2(xy2), f2{-wz2, wz2});                          // fma(x, y2, -+wz2)
+  r.R26 = pfma(lo2(xy), bc2(z2), f2{wxy2.y, -wxy2.y});                     // fma(x, z2, +-wy2)
+  r.R57 = pfma(hi2(xy), bc2(z2), f2{-wxy2.x, wxy2.x});                     // fma(y, z2, -+wx2)
   r.R01 = f2{r.R04.x, r.R13.x}; r.R34 = f2{r.R13.y, r.R04.y}; r.R67 = f2{r.R26.y, r.R57.y};
   const float R0 = r.R04.x, R3 = r.R13.y;
   const float n2 = fma_(R0, R0, R3 * R3);
@@ -802,13 +868,13 @@ DQL_DEV void rot_to_array(const RotPk& r, float (&R)[9]) {
 // constants of the packed tick (register pairs), built once per agent period
 struct PkK {
   f2 kp, ki, lo, hi, wind, sp;     // the two PIDs: (v_z, yaw)
-  f2 kRn, kW01, I01, dtI01;        // kRn = (kR0, -kR1)
+  f2 kRn, kW01, I01, dtI01;        // kRn = (kR0, -kR1) / 2
 };
 template <typename K> DQL_DEV PkK make_pkk(const K& c) {
   PkK k;
   k.kp = mk2(c.vz_kp, c.yw_kp); k.ki = mk2(c.vz_ki, c.yw_ki); k.lo = mk2(c.vz_lo, c.yw_lo); k.hi = mk2(c.vz_hi, c.yw_hi);
   k.wind = mk2(c.vz_wind, c.yw_wind); k.sp = mk2(c.vz_sp, c.yw_sp);
-  k.kRn = mk2(c.kR[0], -c.kR[1]); k.kW01 = mk2(c.kW[0], c.kW[1]); k.I01 = mk2(c.I[0], c.I[1]); k.dtI01 = mk2(c.dtI[0], c.dtI[1]);
+  k.kRn = mk2(0.5f * c.kR[0], -(0.5f * c.kR[1])); k.kW01 = mk2(c.kW[0], c.kW[1]); k.I01 = mk2(c.I[0], c.I[1]); k.dtI01 = mk2(c.dtI[0], c.dtI[1]);
   return k;
 }
 // one 500 Hz physics tick after the rotation (and the manager tick, if due): both PIDs, attitude law, rotor model, rigid body,
@@ -820,10 +886,11 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const f2 e0 = k.sp - s.pid_state;
   const f2 ii = pfma(e0, bc2(c.dt), s.pid_i);
   s.pid_i = f2{clip3(ii.x, -k.wind.x, k.wind.x), clip3(ii.y, -k.wind.y, k.wind.y)};
-  f2 acc = pfma(-bc2(c.bw_k1), s.pid_y3, pfma(bc2(2.0f), s.pid_x1, s.pid_x2) + e0);
-  if (c.bw_k2 != 0) acc = acc - (bc2(c.bw_k2) * s.pid_y2);
-  const f2 fe = bc2(c.bw_inv) * acc;
-  s.pid_x2 = s.pid_x1; s.pid_x1 = e0; s.pid_y3 = s.pid_y2; s.pid_y2 = s.pid_y1; s.pid_y1 = fe;
+  const f2 fe = pfma(bc2(c.bw_inv), e0, s.pid_x1);                           // transposed Butterworth (butterworth(), float32 form)
+  s.pid_x1 = pfma(bc2(c.bw_b2), e0, s.pid_x2);
+  s.pid_x2 = pfma(bc2(c.bw_inv), e0, s.pid_y1);
+  if (c.bw_k2 != 0) s.pid_x2 = pfma(-bc2(c.bw_a2), fe, s.pid_x2);
+  s.pid_y1 = -(bc2(c.bw_a3) * fe);
   const f2 eff = pfma(k.kp, fe, k.ki * s.pid_i);
   const float thrust = clip3(eff.x, k.lo.x, k.hi.x), r_cmd = clip3(eff.y, k.lo.y, k.hi.y);
   // ---- attitude law (attitude_controller.py:107-156): E = B^T A on the yaw-free attitude A (see attitude()) ----
@@ -838,12 +905,12 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const float E12 = fma_(B01.y, A012.y, fma_(B34.y, -sr, B67.y * r.R8));
   const f2 E02_12 = f2{E01_02.y, E12}, E20_21 = f2{E10_20.y, E21_22.x}, E01_10 = f2{E01_02.x, E10_20.x};
   const float E22 = E21_22.y;
-  const f2 hh = bc2(0.5f) * (E02_12 - E20_21);                              // (eR1, -eR0)
-  const float eR2 = 0.5f * (E01_10.y - E01_10.x);
+  const f2 hh = E02_12 - E20_21;                                            // 2 (eR1, -eR0): the halving sits in kRn (exact)
+  const float dR2 = E01_10.y - E01_10.x;
   const f2 eW01 = pfma(-bc2(r_cmd), E02_12, s.w01);
   const float eW2 = fma_(-r_cmd, E22, s.w2);
   const f2 M01 = pfma(-eW01, k.kW01, swp2(hh) * k.kRn);                     // fma(-eW0, kW0, -(eR0 kR0)), fma(-eW1, kW1, -(eR1 kR1))
-  const float M2 = fma_(-eW2, (float)c.kW[2], -(eR2 * c.kR[2]));
+  const float M2 = fma_(-eW2, (float)c.kW[2], -(dR2 * (0.5f * (float)c.kR[2])));
   const float a = thrust * c.ia;
   const f2 ibn = f2{-(float)c.ib, (float)c.ib};
   const f2 w2_02 = pfma(bc2(M2), bc2((float)c.ic), pfma(hi2(M01), ibn, bc2(a)));          // fma(M2, ic, fma(-+M1, ib, a))
@@ -875,9 +942,10 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   s.p01 = pfma(bc2(c.dt), s.v01, s.p01); s.p2 = fma_(c.dt, s.v2, s.p2);
   const float w0 = s.w01.x, w1 = s.w01.y, w2 = s.w2;
   const f2 Iw01 = k.I01 * s.w01; const float Iw2 = c.I[2] * w2;
-  const float g0 = fma_(w1, Iw2, -(w2 * Iw01.y)), g1 = fma_(w2, Iw01.x, -(w0 * Iw2)), g2 = fma_(w0, Iw01.y, -(w1 * Iw01.x));
+  const float g0 = fma_(w1, Iw2, -(w2 * Iw01.y)), g1 = fma_(w2, Iw01.x, -(w0 * Iw2));
   s.w01 = pfma(k.dtI01, txy - f2{g0, g1}, s.w01);
-  s.w2 = fma_((float)c.dtI[2], tz - g2, w2);
+  if ((float)c.I[0] == (float)c.I[1]) s.w2 = fma_((float)c.dtI[2], tz, w2);  // (w x I w)_z = 0 for I_x = I_y (plant_step)
+  else s.w2 = fma_((float)c.dtI[2], tz - fma_(w0, Iw01.y, -(w1 * Iw01.x)), w2);
   {
     const float qw = s.q_wx.x, qx = s.q_wx.y, qy = s.q_yz.x, qz = s.q_yz.y, hdt = 0.5f * c.dt;
     const float nw0 = s.w01.x, nw1 = s.w01.y, nw2 = s.w2;
@@ -901,8 +969,12 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   }
   // ---- platform extrapolation between manager ticks + bumper contact test ----
   s.mp_xy = pfma(s.mp_uv, bc2(c.dt), s.mp_xy);
-  const f2 dxy = s.p01 - s.mp_xy;
-  if (s.p2 - c.bottom <= c.mp_top && abs_(dxy.x) <= c.mp_hx && abs_(dxy.y) <= c.mp_hy) flags |= FL_CONTACT;
+  const bool low = s.p2 - c.bottom <= c.mp_top;
+  if (__ballot(low) != 0ull) {  // see platform_contact
+    asm volatile("; footprint test" ::: "memory");
+    const f2 dxy = s.p01 - s.mp_xy;
+    if (low && abs_(dxy.x) <= c.mp_hx && abs_(dxy.y) <= c.mp_hy) flags |= FL_CONTACT;
+  }
 }
 
 struct StepOut {  // what one env contributes to the shared tables / counters this period

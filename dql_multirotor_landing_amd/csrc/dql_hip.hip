@@ -58,6 +58,8 @@ template <typename T> static MdpK<T> make_mdpk(const dql_config& c) {
   const double step = (c.theta_max - (-c.theta_max)) / 6.0;  // np.linspace(-theta_max, theta_max, 7), pkg/mdp.py:145
   for (int i = 0; i < 6; ++i) d.angles[i] = (T)((double)i * step + (-c.theta_max));
   d.angles[6] = (T)c.theta_max;
+  d.inv_p_max = (T)(1.0 / c.p_max); d.inv_v_max = (T)(1.0 / c.v_max); d.inv_a_max = (T)(1.0 / c.a_max);
+  d.inv_theta_max = (T)(1.0 / c.theta_max); d.dtheta_ratio = (T)(c.delta_theta / c.theta_max);
   d.gamma = c.gamma; d.working = c.working_curriculum_step; d.goal_logic = c.goal_logic; d.quirks = c.quirks;
   return d;
 }
@@ -87,6 +89,7 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   d.yw_kp = (T)c.pid_yaw[0]; d.yw_ki = (T)c.pid_yaw[1]; d.yw_lo = (T)c.pid_yaw[3]; d.yw_hi = (T)c.pid_yaw[4]; d.yw_wind = (T)c.pid_yaw[5]; d.yw_sp = (T)c.yaw_setpoint;
   const double bc = c.bw_c, denom = 1 + bc * bc + 1.414 * bc;  // pkg/filters.py:94-106
   d.bw_inv = (T)(1.0 / denom); d.bw_k1 = (T)(bc * bc - 1.414 * bc + 1); d.bw_k2 = (T)(-2 * bc * bc + 2);
+  d.bw_b2 = (T)(2.0 / denom); d.bw_a2 = (T)((-2 * bc * bc + 2) / denom); d.bw_a3 = (T)((bc * bc - 1.414 * bc + 1) / denom);
   d.mp_dt = (T)c.mp_dt; d.mp_top = (T)c.mp_top_z; d.mp_hx = (T)c.mp_half_x; d.mp_hy = (T)c.mp_half_y; d.bottom = (T)c.drone_bottom;
   d.noise_p = (T)c.noise_pos_sd; d.noise_v = (T)c.noise_vel_sd; d.kal_q = (T)c.kalman_q; d.kal_r = (T)(c.noise_vel_sd * c.noise_vel_sd);
   d.mgr_dt = (T)(c.dt * c.manager_div);
@@ -226,8 +229,8 @@ DQL_DEV long long wave_sum(long long v) {
 // first; the later loads then hit the scalar cache.
 template <int BYTES> DQL_DEV void warm_kernarg() {
   const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
-  constexpr int L = (BYTES + 63) / 64;  // 64-byte lines the arguments reach (9 .. 16); offsets beyond the last line fold back onto it
-  static_assert(L > 8 && L <= 16, "adjust the touch list to the argument size");
+  constexpr int L = (BYTES + 63) / 64;  // 64-byte lines the arguments reach (9 .. 17); offsets beyond the last line fold back onto it (a 17th line — float64 — is left to its first use)
+  static_assert(L > 8 && L <= 17, "adjust the touch list to the argument size");
 #define DQL_LINE(i) ((i) < L ? (i) * 64 : (L - 1) * 64)
   unsigned t0, t1, t2, t3, t4, t5, t6, t7, u0, u1, u2, u3, u4, u5, u6, u7;
   // sixteen loads in flight, one wait.  The first statement's destinations are inputs of the second, so the compiler keeps them allocated

@@ -245,6 +245,7 @@ typedef struct {
   REAL p_max, v_max, a_max, theta_max, delta_theta, beta, sigma_a, min_alt;
   REAL w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   REAL lim_p[5], lim_v[5], lim_a[5], angles[7];
+  REAL inv_p_max, inv_v_max, inv_a_max, inv_theta_max, dtheta_ratio; /* float32 MDP: host reciprocals (round 4) */
   int working, goal_logic;
   uint32_t quirks;
 } mdpc_t;
@@ -262,9 +263,19 @@ static void mdpc_init(mdpc_t* m, const dql_config* c) {
   const double step = (c->theta_max - (-c->theta_max)) / 6.0;
   for (int i = 0; i < 6; ++i) m->angles[i] = (REAL)((double)i * step + (-c->theta_max));
   m->angles[6] = (REAL)c->theta_max;
+  m->inv_p_max = (REAL)(1.0 / c->p_max); m->inv_v_max = (REAL)(1.0 / c->v_max); m->inv_a_max = (REAL)(1.0 / c->a_max);
+  m->inv_theta_max = (REAL)(1.0 / c->theta_max); m->dtheta_ratio = (REAL)(c->delta_theta / c->theta_max);
   m->working = c->working_curriculum_step; m->goal_logic = c->goal_logic;
   m->quirks = c->quirks;
 }
+/* FLOAT32 MDP, ROUND 4: the normalising divisions by the constants p_max, v_max, a_max, theta_max are multiplications by the host's
+ * reciprocals (double division rounded to float once), as in the float32 kernel (csrc/dql_device.hpp, Fast32).  float64 keeps the
+ * reference's divisions: it is what G1 / G2 pin. */
+#if ORACLE_F32
+#define NORM(x, d, inv) ((x) * (inv))
+#else
+#define NORM(x, d, inv) ((x) / (d))
+#endif
 static inline REAL clip(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
 /* The product's 500 Hz clips are one v_med3_f32 each in float (csrc/dql_device.hpp: clip3); restated here from the gfx9 ISA
  * pseudo-code so that even signed-zero ties agree: V_MAX_F32 orders -0 < +0, V_MED3_F32 returns the max of the two operands
@@ -309,9 +320,9 @@ static inline int disc3(REAL v, REAL goal, REAL limit) {
 }
 /* pkg/mdp.py:257-333 -> packed index ((((k*3+p)*3+v)*3+a)*7+theta), or -1 */
 static int discretise(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL angle) {
-  const REAL cp = clip(rel_p / m->p_max, R_(-1.0), R_(1.0));
-  const REAL cv = clip(rel_v / m->v_max, R_(-1.0), R_(1.0));
-  const REAL ca = clip(rel_a / m->a_max, R_(-1.0), R_(1.0));
+  const REAL cp = clip(NORM(rel_p, m->p_max, m->inv_p_max), R_(-1.0), R_(1.0));
+  const REAL cv = clip(NORM(rel_v, m->v_max, m->inv_v_max), R_(-1.0), R_(1.0));
+  const REAL ca = clip(NORM(rel_a, m->a_max, m->inv_a_max), R_(-1.0), R_(1.0));
   const int n = m->working + 1;
   int k = latest_valid_level(m->lim_p, n, cp);
   const int kv = latest_valid_level(m->lim_v, n, cv), ka = latest_valid_level(m->lim_a, n, ca);
@@ -369,20 +380,24 @@ static int mdp_check(const mdpc_t* m, int* step_count, int* cur_check, int code,
 }
 /* pkg/mdp.py:441-541; shp = persistent "current_shaping_value" (position, velocity, angle) */
 static REAL mdp_reward(const mdpc_t* m, REAL* shp, REAL* cum, int code, int cur_idx, REAL rel_p, REAL rel_v, REAL angle_sp) {
-  const REAL ncp = clip(rel_p / m->p_max, R_(-1.0), R_(1.0));
-  const REAL ncv = clip(rel_v / m->v_max, R_(-1.0), R_(1.0));
-  const REAL npitch = angle_sp / m->theta_max;
+  const REAL ncp = clip(NORM(rel_p, m->p_max, m->inv_p_max), R_(-1.0), R_(1.0));
+  const REAL ncv = clip(NORM(rel_v, m->v_max, m->inv_v_max), R_(-1.0), R_(1.0));
+  const REAL npitch = NORM(angle_sp, m->theta_max, m->inv_theta_max);
   const int k = idx_level(cur_idx);
   const REAL prev_p = shp[0], prev_v = shp[1], prev_a = shp[2];
   shp[0] = m->w_p * FABS(ncp); shp[1] = m->w_v * FABS(ncv); shp[2] = m->w_theta * FABS(npitch);
   const REAL r_p_max = FABS(m->w_p) * m->lim_v[k] * m->delta_t;
   const REAL r_v_max = FABS(m->w_v) * m->lim_a[k] * m->delta_t;
+#if ORACLE_F32
+  const REAL r_theta_max = FABS(m->w_theta) * m->dtheta_ratio * m->lim_v[k];
+#else
   const REAL r_theta_max = FABS(m->w_theta) * (m->delta_theta / m->theta_max) * m->lim_v[k];
+#endif
   const REAL r_dur_max = m->w_dur * m->lim_v[k] * m->delta_t;
   const REAL r_max = r_p_max + r_v_max + r_theta_max + r_dur_max;
   const REAL r_p = clip(shp[0] - prev_p, -r_p_max, r_p_max);
   const REAL r_v = clip(shp[1] - prev_v, -r_v_max, r_v_max);
-  const REAL r_theta = m->w_theta * (FABS(shp[2]) - FABS(prev_a)) / m->theta_max * m->lim_v[k];
+  const REAL r_theta = NORM(m->w_theta * (FABS(shp[2]) - FABS(prev_a)), m->theta_max, m->inv_theta_max) * m->lim_v[k];
   const REAL r_dur = m->w_dur * m->lim_v[k] * m->delta_t;
   REAL r_term;
   if (code == DQL_NON_TERMINAL_SUCCESS || code == DQL_TERMINAL_SUCCESS) r_term = m->w_succ * r_max;
@@ -406,12 +421,14 @@ static inline int agent_predict(const double* qa, const double* qb, int idx) {
 /* ------------------------------------------------------------------------------------------------
  * filters / PID — pkg/filters.py, pkg/pid.py
  * ---------------------------------------------------------------------------------------------- */
-typedef struct { REAL k1, k2, inv_denom; } bwc_t;
+typedef struct { REAL k1, k2, inv_denom, b2, a2, a3; } bwc_t;
 static void bwc_init(bwc_t* b, double c) {
   const double denom = 1 + c * c + 1.414 * c;             /* pkg/filters.py:94 */
   b->inv_denom = (REAL)(1.0 / denom);                      /* :103 */
   b->k1 = (REAL)(c * c - 1.414 * c + 1);                   /* :105 */
   b->k2 = (REAL)(-2 * c * c + 2);                          /* :106 */
+  /* float32 (round 4): the same transfer function b (1 + 2 z^-1 + z^-2) / (1 + a2 z^-2 + a3 z^-3) in TRANSPOSED form */
+  b->b2 = (REAL)(2.0 / denom); b->a2 = (REAL)((-2 * c * c + 2) / denom); b->a3 = (REAL)((c * c - 1.414 * c + 1) / denom);
 }
 /* pkg/filters.py:98-109; history x1,x2 = previous two inputs, y1..y3 = previous three outputs (the deque keeps 3) */
 static inline REAL butterworth(const bwc_t* b, REAL x0, REAL* x1, REAL* x2, REAL* y1, REAL* y2, REAL* y3) {
@@ -420,15 +437,26 @@ static inline REAL butterworth(const bwc_t* b, REAL x0, REAL* x1, REAL* x2, REAL
    * correctly-rounded-per-operation form (products folded into the additions that consume them, dt/m, dt g, dt/I multiplied out on
    * the host, two Newton steps from a second-order start in yaw_cs), exactly as the float32 kernel does: ORACLE_F32 below. */
 #if ORACLE_F32
-  REAL acc = FMA(-b->k1, *y3, FMA(R_(2.0), *x1, *x2) + x0);
+  /* FLOAT32 TICK, ROUND 4: y[n] = b (x[n] + 2 x[n-1] + x[n-2]) - a2 y[n-2] - a3 y[n-3] (the reference's recurrence, deque of three included)
+   * as a transposed direct form: y = b x + t1; t1 = 2b x + t2; t2 = b x - a2 y + t3; t3 = -a3 y.  Three states instead of five histories and no
+   * history shifts (ten register moves per physics tick in the kernel's rolled loop).  States: t1, t2, t3 live in the fields x1, x2, y1; y2, y3
+   * are not used.  The reference's histories (x1, x2 = last two inputs, y1..y3 = last three outputs) map to them as t1 = 2b x1 + b x2 - a2 y2 - a3 y3,
+   * t2 = b x1 - a2 y1 - a3 y2, t3 = -a3 y1 (tests/test_gpu_parity.py: to_f32_filter_state). */
+  (void)y2; (void)y3;
+  const REAL value = FMA(b->inv_denom, x0, *x1);
+  *x1 = FMA(b->b2, x0, *x2);
+  *x2 = FMA(b->inv_denom, x0, *y1);
+  if (b->k2 != R_(0.0)) *x2 = FMA(-b->a2, value, *x2);
+  *y1 = -(b->a3 * value);
+  return value;
 #else
   REAL acc = *x2 + R_(2.0) * *x1 + x0 - b->k1 * *y3;
-#endif
   if (b->k2 != R_(0.0)) acc = acc - (b->k2 * *y2); /* -2c^2 + 2 is exactly 0 for the reference's c = 1 (pkg/filters.py:93,106) */
   const REAL value = b->inv_denom * acc;
   *x2 = *x1; *x1 = x0;
   *y3 = *y2; *y2 = *y1; *y1 = value;
   return value;
+#endif
 }
 typedef struct { REAL kp, ki, kd, lo, hi, windup, setpoint; } pidc_t;
 /* pkg/pid.py:62-104 with delta_t > 0 */
@@ -510,6 +538,16 @@ static void simc_init(simc_t* s, const dql_config* c) {
 /* rotation matrix of a unit quaternion (w, x, y, z) */
 static inline void quat_to_R(const REAL* q, REAL R[9]) {
   const REAL w = q[0], x = q[1], y = q[2], z = q[3];
+#if ORACLE_F32 /* round 4: the factor 2 applied once to x, y, z (exact), every entry one or two fused multiply-adds: 17 operations instead of 30 */
+  const REAL x2 = x + x, y2 = y + y, z2 = z + z;
+  const REAL t = FMA(-z, z2, R_(1.0));
+  R[0] = FMA(-y, y2, t); R[4] = FMA(-x, x2, t); R[8] = FMA(-x, x2, FMA(-y, y2, R_(1.0)));
+  const REAL wx2 = w * x2, wy2 = w * y2, wz2 = w * z2;
+  R[1] = FMA(x, y2, -wz2); R[3] = FMA(x, y2, wz2);
+  R[2] = FMA(x, z2, wy2); R[6] = FMA(x, z2, -wy2);
+  R[5] = FMA(y, z2, -wx2); R[7] = FMA(y, z2, wx2);
+  return;
+#endif
   const REAL xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
   R[0] = R_(1.0) - R_(2.0) * (yy + zz); R[1] = R_(2.0) * (xy - wz); R[2] = R_(2.0) * (xz + wy);
   R[3] = R_(2.0) * (xy + wz); R[4] = R_(1.0) - R_(2.0) * (xx + zz); R[5] = R_(2.0) * (yz - wx);
@@ -521,10 +559,10 @@ static inline void quat_to_R(const REAL* q, REAL R[9]) {
 static inline void yaw_cs4(const REAL R[9], REAL* c, REAL* s, REAL* ct, REAL* rn) {
   const REAL n2 = FMA(R[0], R[0], R[3] * R[3]);
   const REAL h = R_(-0.5) * n2;
-#if ORACLE_F32 /* second-order start 1 + d/2 + 3 d^2/8, d = 1 - n2, then two Newton steps */
+#if ORACLE_F32 /* second-order start 1 + d/2 + 3 d^2/8, d = 1 - n2, then THREE Newton steps (round 4; two left 0.5 % at a tilt of 60 deg) */
   const REAL d = R_(1.0) - n2;
   REAL r = FMA(FMA(R_(0.375), d, R_(0.5)), d, R_(1.0));
-  for (int k = 0; k < 2; ++k) r = r * FMA(h * r, r, R_(1.5));
+  for (int k = 0; k < 3; ++k) r = r * FMA(h * r, r, R_(1.5));
 #else
   REAL r = FMA(R_(-0.5), n2, R_(1.5));
   for (int k = 0; k < 5; ++k) r = r * FMA(h * r, r, R_(1.5));
@@ -626,7 +664,10 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   const REAL g0 = FMA(w[1], Iw2, -(w[2] * Iw1)), g1 = FMA(w[2], Iw0, -(w[0] * Iw2)), g2 = FMA(w[0], Iw1, -(w[1] * Iw0));
 #if ORACLE_F32
   { const REAL w0 = w[0], w1 = w[1], w2_ = w[2];
-    e->w[0] = FMA(s->dtI[0], tx - g0, w0); e->w[1] = FMA(s->dtI[1], ty - g1, w1); e->w[2] = FMA(s->dtI[2], tz - g2, w2_); }
+    e->w[0] = FMA(s->dtI[0], tx - g0, w0); e->w[1] = FMA(s->dtI[1], ty - g1, w1);
+    /* round 4: (w x I w)_z = (I_y - I_x) w_x w_y is exactly 0 for a vehicle with I_x = I_y (the reference's): not computed */
+    if (s->I[0] == s->I[1]) e->w[2] = FMA(s->dtI[2], tz, w2_);
+    else e->w[2] = FMA(s->dtI[2], tz - g2, w2_); }
 #else
   e->w[0] = FMA(s->dt, (tx - g0) * s->inv_I[0], w[0]);
   e->w[1] = FMA(s->dt, (ty - g1) * s->inv_I[1], w[1]);

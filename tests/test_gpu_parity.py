@@ -112,28 +112,52 @@ def test_external_actions_and_eval(mods):
         eng.step(np.full(n, 3, dtype=np.uint8))
 
 
+def to_f32_filter_state(reals, names, bw_c=1.0):
+    """float64 env state -> the float32 layouts' state.  The only fields whose MEANING differs between the dtypes are the two PIDs' Butterworth
+    filters: float64 keeps the reference's histories (x1, x2 = last two inputs, y1 .. y3 = last three outputs, pkg/filters.py:98-109), float32
+    the three states of the same recurrence in transposed form, stored in (x1, x2, y1) with y2 = y3 = 0 (csrc/dql_device.hpp butterworth):
+    t1 = 2b x1 + b x2 - a2 y2 - a3 y3,  t2 = b x1 - a2 y1 - a3 y2,  t3 = -a3 y1."""
+    r = np.array(reals, dtype=np.float64, copy=True)
+    denom = 1 + bw_c * bw_c + 1.414 * bw_c
+    b, a2, a3 = 1.0 / denom, (-2 * bw_c * bw_c + 2) / denom, (bw_c * bw_c - 1.414 * bw_c + 1) / denom
+    for pfx in ("vz_", "yw_"):
+        x1, x2, y1, y2, y3 = (reals[names.index(pfx + k)] for k in ("x1", "x2", "y1", "y2", "y3"))
+        r[names.index(pfx + "x1")] = 2 * b * x1 + b * x2 - a2 * y2 - a3 * y3
+        r[names.index(pfx + "x2")] = b * x1 - a2 * y1 - a3 * y2
+        r[names.index(pfx + "y1")] = -a3 * y1
+        r[names.index(pfx + "y2")] = 0.0
+        r[names.index(pfx + "y3")] = 0.0
+    return r
+
+
 def test_f32_kernel_vs_f64_oracle_one_period(mods):
     """north_star tolerance: continuous dynamics within 1e-5 relative (float32 kernel vs float64 oracle, one agent
-    period from identical states); discrete indices equal except inputs within rounding distance of a bin edge."""
+    period from identical states); discrete indices equal except inputs within rounding distance of a bin edge.
+    The common state is flown by the float64 oracle (50 periods) and handed to the float32 engine (filter states mapped, to_f32_filter_state)."""
     Engine, Oracle = mods
     n = 2048
+    o64 = Oracle(DqlConfig(dtype=F64), n, seed=9, n_threads=8)
+    o64.train_steps(50, 1.0)
+    reals, ints = o64.get_fields()
     e32 = Engine(DqlConfig(dtype=F32), n, seed=9)
-    e32.train_steps(50, 1.0)
-    reals, ints = e32.get_fields()
-    o64 = Oracle(DqlConfig(dtype=F64), n, seed=9)
-    o64.train_steps(50, 1.0)  # advance the schedule identically, then overwrite tables and env state
-    qa32, qb32, cnt32 = e32.get_tables()
-    e32.set_tables(qa32, qb32, cnt32)  # master == acting on both sides from here
-    o64.set_tables(qa32, qb32, cnt32)
-    o64.set_fields(reals, ints)
+    e32.train_steps(50, 1.0)  # advance the schedule identically, then overwrite tables and env state
+    names = e32.field_names()
+    qa, qb, cnt = o64.qa.copy(), o64.qb.copy(), o64.count.copy()
+    e32.set_tables(qa, qb, cnt)  # master == acting on both sides from here
+    o64.set_tables(qa, qb, cnt)
+    e32.set_fields(to_f32_filter_state(reals, names), ints)
     e32.train_steps(1, 1.0); o64.train_steps(1, 1.0)
     r32, i32 = e32.get_fields(); r64, i64 = o64.get_fields()
-    names = e32.field_names()
     dyn = [names.index(k) for k in ("px", "py", "pz", "vx", "vy", "vz", "qw", "qx", "qy", "qz", "om0", "om1", "om2", "om3", "mp_x", "mp_u")]
     for k in dyn:
         scale = np.maximum(np.abs(r64[k]), 1.0)
         assert (np.abs(r32[k] - r64[k]) / scale).max() < 1e-5, names[k]
     assert (i32[0] != i64[0]).mean() < 5e-3
+    # the mapped filter states are the same filters: after the period they still describe the float64 histories
+    want = to_f32_filter_state(r64, names)
+    for k in ("vz_x1", "vz_x2", "vz_y1", "yw_x1", "yw_x2", "yw_y1"):
+        j = names.index(k)
+        np.testing.assert_allclose(r32[j], want[j], rtol=2e-4, atol=2e-5, err_msg=k)
 
 
 def test_curriculum_switch_and_transfer(mods):

@@ -141,13 +141,12 @@ def test_g9_attitude(golden_dir):
     np.testing.assert_allclose(rot, g["rotor"], rtol=1e-10, atol=1e-7)
     assert (g["rotor"][20:30] == 0).any(), "fixture exercises the clamp at zero"
     mom32, rot32 = orc.attitude_run(DqlConfig(dtype=F32), g["quat_xyzw"], g["omega"], g["cmd"], dtype=0)
-    # float32 tick (round 3): the yaw frame is normalised by two Newton steps from a second-order start — converged to rounding for the tilts
-    # a controlled vehicle reaches (set-point <= 21.4 deg), 2e-5 at 45 deg, under 1 % at the fixture's most tilted sample (60 deg: tumbling)
+    # float32 tick: the yaw frame is normalised by THREE Newton steps from a second-order start (round 4; round 3's two left 2e-5 at a tilt of 45 deg
+    # and 0.5 % at the fixture's most tilted sample, 60 deg): one tolerance over the whole fixture again
     x, y, z, w = g["quat_xyzw"].T
     tilt = np.degrees(np.arccos(np.sqrt(np.clip((1 - 2 * (y * y + z * z)) ** 2 + (2 * (x * y + w * z)) ** 2, 0, 1))))
     assert (tilt <= 45).sum() > 150 and tilt.max() > 55
-    np.testing.assert_allclose(mom32[tilt <= 45], g["moment"][tilt <= 45], rtol=2e-4, atol=2e-6)
-    np.testing.assert_allclose(mom32, g["moment"], rtol=1e-2, atol=2e-5)
+    np.testing.assert_allclose(mom32, g["moment"], rtol=2e-4, atol=2e-6)
 
 
 def test_g11_platform(golden_dir):
