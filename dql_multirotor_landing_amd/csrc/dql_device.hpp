@@ -579,12 +579,30 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s, T& ct, T&
 // float32 (Fast32): E = R_des^T R with R_des = Rz(yaw) B and R = Rz(yaw) A, A = Ry(pitch) Rx(roll) the yaw-free attitude, is B^T A — and A needs
 // no yaw at all: its last row is R's, A00 = cos(pitch) = sqrt(R00^2 + R10^2) = ct, A10 = 0, sin / cos(roll) = R21 / ct, R22 / ct = R7 rn, R8 rn,
 // sin(pitch) = -R20.  5 multiplications + 19 for the seven entries instead of 2 + 12 (R_des) + 21; cy, sy are only needed by the manager tick.
+// xonly (float32, round 4): an x-axis config flies with a roll set-point of exactly 0, so B = Ry(pitch_sp) = [[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]] and the
+// seven entries collapse: E10 = 0, E12 = -sin(roll), the others lose their middle term — 14 instructions instead of 24, and B is two registers, not nine.
+// Compile-time in the layouts the host selects by itself (k_step's XMODE), a wave-uniform test in the others; the oracle takes the same form.
 template <typename T, typename K>
-DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T ct, T rn, T r_cmd, T thrust, T (&cmd)[4]) {
+DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)[9], T cy, T sy, T ct, T rn, T r_cmd, T thrust, T (&cmd)[4], bool xonly = false) {
   T E01, E10, E02, E20, E12, E21, E22;
   if constexpr (Fast32<T>::on) {
     const T sr = R[7] * rn, cr = R[8] * rn;             // sin, cos of the roll angle
     const T A01 = -(R[6] * sr), A02 = -(R[6] * cr);     // sin(pitch) sin(roll), sin(pitch) cos(roll)
+    if (xonly) {
+      const T cp = B[0], sp = B[2];
+      E01 = fma_(cp, A01, -(sp * R[7])); E02 = fma_(cp, A02, -(sp * R[8]));
+      E20 = fma_(sp, ct, cp * R[6]); E21 = fma_(sp, A01, cp * R[7]); E22 = fma_(sp, A02, cp * R[8]);
+      const T dR0 = E21 + sr, dR1 = E02 - E20;          // E12 = -sr, E10 = 0: dR2 = -E01
+      const T eW0 = fma_(-r_cmd, E02, w[0]), eW1 = fma_(r_cmd, sr, w[1]), eW2 = fma_(-r_cmd, E22, w[2]);
+      const T M0 = fma_(-eW0, T(s.kW[0]), -(dR0 * (T(0.5) * T(s.kR[0]))));
+      const T M1 = fma_(-eW1, T(s.kW[1]), -(dR1 * (T(0.5) * T(s.kR[1]))));
+      const T M2 = fma_(-eW2, T(s.kW[2]), E01 * (T(0.5) * T(s.kR[2])));
+      const T a = thrust * s.ia;
+      const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cmd[i] = sqrt_pos(w2[i] > SQRT_POS_MIN ? w2[i] : SQRT_POS_MIN);
+      return;
+    }
     E01 = fma_(B[0], A01, fma_(B[3], cr, B[6] * R[7]));
     E02 = fma_(B[0], A02, fma_(B[3], -sr, B[6] * R[8]));
     E10 = fma_(B[1], ct, B[7] * R[6]);
@@ -879,7 +897,7 @@ template <typename K> DQL_DEV PkK make_pkk(const K& c) {
 }
 // one 500 Hz physics tick after the rotation (and the manager tick, if due): both PIDs, attitude law, rotor model, rigid body,
 // rotor filter, platform extrapolation + contact test.  B = Rx(roll_sp) Ry(pitch_sp) as pairs B01, B34, B67 and scalars B2, B5, B8.
-template <typename K>
+template <bool XONLY, typename K>
 DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r, const f2 B01, const f2 B34, const f2 B67, const float B2,
                              const float B5, const float B8, int& flags) {
   // ---- pid_output x 2 (pid.py:62-104, Kd = 0) ----
@@ -899,14 +917,26 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const f2 A012 = f2{-(R6 * sr), -(R6 * cr)};                                            // (A01, A02)
   const f2 crsr = f2{cr, -sr};                                                            // (A11, A12)
   const f2 R78 = f2{R7, r.R8};                                                            // (A21, A22)
-  const f2 E01_02 = pfma(lo2(B01), A012, pfma(lo2(B34), crsr, lo2(B67) * R78));           // (E01, E02)
-  const f2 E21_22 = pfma(bc2(B2), A012, pfma(bc2(B5), crsr, bc2(B8) * R78));              // (E21, E22)
-  const f2 E10_20 = pfma(f2{B01.y, B2}, bc2(r.ct), f2{B67.y, B8} * bc2(R6));              // (E10, E20)
-  const float E12 = fma_(B01.y, A012.y, fma_(B34.y, -sr, B67.y * r.R8));
-  const f2 E02_12 = f2{E01_02.y, E12}, E20_21 = f2{E10_20.y, E21_22.x}, E01_10 = f2{E01_02.x, E10_20.x};
-  const float E22 = E21_22.y;
-  const f2 hh = E02_12 - E20_21;                                            // 2 (eR1, -eR0): the halving sits in kRn (exact)
-  const float dR2 = E01_10.y - E01_10.x;
+  f2 hh, E02_12; float dR2, E22;
+  if constexpr (XONLY) {  // B = Ry(pitch_sp): attitude(), xonly
+    const f2 cp2 = lo2(B01), sp2 = bc2(B2);
+    const f2 E01_02 = pfma(cp2, A012, -(sp2 * R78));                                      // fma(cp, A01, -(sp R7)), fma(cp, A02, -(sp R8))
+    const f2 E21_22 = pfma(sp2, A012, cp2 * R78);                                         // fma(sp, A01, cp R7), fma(sp, A02, cp R8)
+    const float E20 = fma_(B2, r.ct, B01.x * R6);
+    E02_12 = f2{E01_02.y, -sr};                                                           // E12 = -sin(roll)
+    hh = E02_12 - f2{E20, E21_22.x};                                                      // (dR1, -dR0) = (E02 - E20, -(E21 + sr))
+    dR2 = -E01_02.x; E22 = E21_22.y;
+  } else {
+    const f2 E01_02 = pfma(lo2(B01), A012, pfma(lo2(B34), crsr, lo2(B67) * R78));           // (E01, E02)
+    const f2 E21_22 = pfma(bc2(B2), A012, pfma(bc2(B5), crsr, bc2(B8) * R78));              // (E21, E22)
+    const f2 E10_20 = pfma(f2{B01.y, B2}, bc2(r.ct), f2{B67.y, B8} * bc2(R6));              // (E10, E20)
+    const float E12 = fma_(B01.y, A012.y, fma_(B34.y, -sr, B67.y * r.R8));
+    E02_12 = f2{E01_02.y, E12};
+    const f2 E20_21 = f2{E10_20.y, E21_22.x}, E01_10 = f2{E01_02.x, E10_20.x};
+    E22 = E21_22.y;
+    hh = E02_12 - E20_21;                                                     // 2 (eR1, -eR0): the halving sits in kRn (exact)
+    dR2 = E01_10.y - E01_10.x;
+  }
   const f2 eW01 = pfma(-bc2(r_cmd), E02_12, s.w01);
   const float eW2 = fma_(-r_cmd, E22, s.w2);
   const f2 M01 = pfma(-eW01, k.kW01, swp2(hh) * k.kRn);                     // fma(-eW0, kW0, -(eR0 kR0)), fma(-eW1, kW1, -(eR1 kR1))
@@ -1169,7 +1199,11 @@ template <int TICK, typename T> struct TickConsts {
     if constexpr (sizeof(T) == 4 && TICK == TICK_PACKED) pk = make_pkk(h);
   }
 };
-template <int TICK, typename T, typename TabPtr>
+// XMODE: what the kernel knows about the config's axes at compile time.  X_TWO: a two-axis config (generic attitude law); X_ONLY: an x-axis config
+// (roll set-point exactly 0: attitude()'s xonly form, and the y-axis state is dead code — the caller passes a SimK whose two_axis is the
+// constant 0); X_RUNTIME: decided by s.two_axis (wave-uniform), both forms in the code — the layouts the host does not pick by itself.
+enum { X_TWO = 0, X_ONLY = 1, X_RUNTIME = 2 };
+template <int TICK, int XMODE, typename T, typename TabPtr>
 DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
                              int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
   const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
@@ -1200,7 +1234,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, h.yw_lo, h.yw_hi, h.yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
     DQL_SECTION("attitude");
-    attitude(h, R, e.w, B, cy, sy, ct, rn, r_cmd, thrust, cmd);
+    attitude(h, R, e.w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, XMODE == X_ONLY || (XMODE == X_RUNTIME && s.two_axis == 0));
     DQL_SECTION("motor_body");
     plant_step(h, e, R);
     rotor_filter(h, e, cmd);
@@ -1234,7 +1268,10 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
         ts.pid_state = mk2(e.vz_state, e.yw_state); ts.mp_xy = mk2(e.mp_x, e.mp_y); ts.mp_uv = mk2(e.mp_u, e.mp_v);
       }
       DQL_SECTION("tick_pk");
-      physics_tick_pk(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
+      if constexpr (XMODE == X_RUNTIME) {
+        if (s.two_axis == 0) physics_tick_pk<true>(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
+        else physics_tick_pk<false>(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
+      } else physics_tick_pk<XMODE == X_ONLY>(h, pk, ts, rp, B01, B34, B67, B2, B5, B8, e.flags);
     };
     if constexpr (!HOT) {
 #pragma unroll TickUnroll<T>::n

@@ -252,7 +252,8 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
 // 64 .. 256 threads: at most 2 waves per SIMD (68 KB of LDS accumulators per workgroup, or the register-hungry layouts); 512 threads:
 // two workgroups per CU = 4 waves per SIMD, so the compiler must stay within 128 VGPRs (it parks ~35 cold values in scratch)
 constexpr int step_waves_per_simd(int block) { return block == 512 ? 4 : 2; }
-template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
+template <typename T> DQL_DEV SimK<T> x_only(SimK<T> c) { c.two_axis = 0; return c; }
+template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)
@@ -305,7 +306,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     // no previous state (idx -1): its row is never used, but the address must stay inside the table
     const int4 iv = a.si[i];
     qx = load_qrow(a.qa, a.qb, (unsigned)iv.x < (unsigned)(DQL_N_CELLS / DQL_N_ACTIONS) ? iv.x : 0);
-    load_env(e, a.sr, iv, a.n, i, a.c);
+    load_env(e, a.sr, iv, a.n, i, XMODE == X_ONLY ? x_only(a.c) : a.c);
     DQL_MARK_T(e, 2);
 #ifdef DQL_PHASE_CLOCK
     for (int k = 0; k < 7; ++k) e.ph[k] = 0;
@@ -317,7 +318,10 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
   // terminal histogram of the wave over the launch: one ballot per CheckResult code and period instead of one global atomic per finished
   // episode (thousands per period on a handful of addresses at large batches)
   unsigned code_w[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  const TickConsts<TICK, T> tc(a.c);
+  // XMODE (dql_device.hpp agent_period): in an x-axis kernel the config's two_axis is the constant 0 — every y-axis branch of the step folds away
+  SimK<T> cfgk = a.c;
+  if constexpr (XMODE == X_ONLY) cfgk.two_axis = 0;
+  const TickConsts<TICK, T> tc(cfgk);
   for (int p = 0; p < a.n_periods; ++p) {
     dec = 0; don = 0; rfx = 0; goal = false;
     int done_code = -1;
@@ -327,7 +331,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
         const int ax = ext & 3, ay = (ext >> 2) & 3;
         if (ax > 2 || ay > 2 || (ext >> 4) || (!a.c.two_axis && ay != 0 && ay != 2)) atomicAdd(&a.stats->bad_actions, 1ull);
       }
-      const StepOut o = agent_period<TICK>(a.c, tc, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
+      const StepOut o = agent_period<TICK, XMODE>(cfgk, tc, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
         if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
@@ -359,7 +363,7 @@ template <typename T, int BLOCK, int TICK> __global__ __launch_bounds__(BLOCK) _
     }
   }
   if (i < a.n) {
-    store_env(e, a.sr, a.si, a.n, i, a.c);  // the atomics went out first: their round trip hides behind the state stores
+    store_env(e, a.sr, a.si, a.n, i, XMODE == X_ONLY ? x_only(a.c) : a.c);  // the atomics went out first: their round trip hides behind the state stores
     DQL_MARK_T(e, 6);
 #ifdef DQL_WAVE_CLOCK
     clk1 = e.mark;
@@ -824,7 +828,12 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
 template <typename T, int BLOCK, int TICK> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
   const StepArgs<T> a = make_step_args<T>(x, mode, eps, BLOCK, n_periods);
   const int writer_blocks = (DQL_N_CELLS + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((k_step<T, BLOCK, TICK>), dim3((unsigned)(a.env_blocks + writer_blocks)), dim3(BLOCK), 0, x->stream, a);
+  const dim3 grid((unsigned)(a.env_blocks + writer_blocks)), block(BLOCK);
+  // the layouts launch_step_b picks by itself come in an x-axis and a two-axis instance (agent_period's XMODE); the others decide at run time
+  if constexpr (sizeof(T) == 4 && (TICK == TICK_LIT || TICK == TICK_PACKED)) {
+    if (x->cfg.two_axis) hipLaunchKernelGGL((k_step<T, BLOCK, TICK, X_TWO>), grid, block, 0, x->stream, a);
+    else hipLaunchKernelGGL((k_step<T, BLOCK, TICK, X_ONLY>), grid, block, 0, x->stream, a);
+  } else hipLaunchKernelGGL((k_step<T, BLOCK, TICK, X_RUNTIME>), grid, block, 0, x->stream, a);
 }
 // Which k_step variant serves a launch (options "block" and "tick"; 0 = auto).  Measured on MI355X, periods_per_launch 4
 // (profiles/r2_sweep_tick.jsonl, r2_sweep_occupancy.jsonl):

@@ -572,30 +572,44 @@ static inline void yaw_cs4(const REAL R[9], REAL* c, REAL* s, REAL* ct, REAL* rn
 static inline void yaw_cs(const REAL R[9], REAL* c, REAL* s) { REAL ct, rn; yaw_cs4(R, c, s, &ct, &rn); }
 
 /* pkg/attitude_controller.py:107-156: (R, body rates, B = Rx(roll_sp) Ry(pitch_sp), yaw rate cmd, thrust) -> rotor speed commands */
+/* xonly (float32, round 4): the caller flies an x-axis config — roll set-point exactly 0, B = Ry(pitch_sp) — and the float32 kernel then takes the
+ * collapsed form of E (csrc/dql_device.hpp attitude(): E10 = 0, E12 = -sin(roll), no middle terms) */
 static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], const REAL B[9], REAL cy, REAL sy, REAL ct, REAL rn, REAL r_cmd, REAL thrust,
-                            REAL cmd[4], REAL M[3]) {
+                            REAL cmd[4], REAL M[3], int xonly) {
 #if ORACLE_F32
   /* float32 tick: E = R_des^T R = B^T A on the yaw-free attitude A = Ry(pitch) Rx(roll): last row = R's, A00 = ct, A10 = 0,
    * sin / cos(roll) = R7 rn, R8 rn, sin(pitch) = -R6 (csrc/dql_device.hpp attitude()) */
   (void)cy; (void)sy;
   const REAL sr = R[7] * rn, cr = R[8] * rn;
   const REAL A01 = -(R[6] * sr), A02 = -(R[6] * cr);
-  const REAL E01 = FMA(B[0], A01, FMA(B[3], cr, B[6] * R[7]));
-  const REAL E02 = FMA(B[0], A02, FMA(B[3], -sr, B[6] * R[8]));
-  const REAL E10 = FMA(B[1], ct, B[7] * R[6]);
-  const REAL E12 = FMA(B[1], A02, FMA(B[4], -sr, B[7] * R[8]));
-  const REAL E20 = FMA(B[2], ct, B[8] * R[6]);
-  const REAL E21 = FMA(B[2], A01, FMA(B[5], cr, B[8] * R[7]));
-  const REAL E22 = FMA(B[2], A02, FMA(B[5], -sr, B[8] * R[8]));
+  REAL E01, E02, E10, E12, E20, E21, E22;
+  if (xonly) {
+    const REAL cp = B[0], sp = B[2];
+    E01 = FMA(cp, A01, -(sp * R[7])); E02 = FMA(cp, A02, -(sp * R[8]));
+    E10 = R_(0.0); E12 = -sr;
+    E20 = FMA(sp, ct, cp * R[6]); E21 = FMA(sp, A01, cp * R[7]); E22 = FMA(sp, A02, cp * R[8]);
+  } else {
+    E01 = FMA(B[0], A01, FMA(B[3], cr, B[6] * R[7]));
+    E02 = FMA(B[0], A02, FMA(B[3], -sr, B[6] * R[8]));
+    E10 = FMA(B[1], ct, B[7] * R[6]);
+    E12 = FMA(B[1], A02, FMA(B[4], -sr, B[7] * R[8]));
+    E20 = FMA(B[2], ct, B[8] * R[6]);
+    E21 = FMA(B[2], A01, FMA(B[5], cr, B[8] * R[7]));
+    E22 = FMA(B[2], A02, FMA(B[5], -sr, B[8] * R[8]));
+  }
 #else
-  (void)ct; (void)rn;
+  (void)ct; (void)rn; (void)xonly;
   REAL D[9]; /* R_des = Rz(yaw) B */
   for (int j = 0; j < 3; ++j) { D[j] = FMA(cy, B[j], -(sy * B[3 + j])); D[3 + j] = FMA(sy, B[j], cy * B[3 + j]); D[6 + j] = B[6 + j]; }
 #define E_(i, j) FMA(D[i], R[j], FMA(D[3 + i], R[3 + j], D[6 + i] * R[6 + j])) /* (R_des^T R)_ij */
   const REAL E01 = E_(0, 1), E10 = E_(1, 0), E02 = E_(0, 2), E20 = E_(2, 0), E12 = E_(1, 2), E21 = E_(2, 1), E22 = E_(2, 2);
 #undef E_
 #endif
+#if ORACLE_F32 /* xonly: the kernel forms -E01 directly (E10 - E01 with E10 = +0 would turn a zero E01 into +0 instead of -0) */
+  const REAL eR0 = R_(0.5) * (E21 - E12), eR1 = R_(0.5) * (E02 - E20), eR2 = R_(0.5) * (xonly ? -E01 : E10 - E01);
+#else
   const REAL eR0 = R_(0.5) * (E21 - E12), eR1 = R_(0.5) * (E02 - E20), eR2 = R_(0.5) * (E10 - E01);
+#endif
 #if ORACLE_F32
   const REAL eW0 = FMA(-r_cmd, E02, w[0]), eW1 = FMA(-r_cmd, E12, w[1]), eW2 = FMA(-r_cmd, E22, w[2]);
   M[0] = FMA(-eW0, s->kW[0], -(eR0 * s->kR[0]));
@@ -837,7 +851,7 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
     const REAL thrust = pid_output(&s->pvz, &s->bw, &e->vz, s->dt);
     const REAL r_cmd = pid_output(&s->pyaw, &s->bw, &e->yaw, s->dt);
     REAL cmd[4], M[3];
-    attitude(s, R, e->w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, M);
+    attitude(s, R, e->w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, M, !s->two_axis);
     motor_and_body(s, e, R, cmd);
     e->mp_x = FMA(e->mp_u, s->dt, e->mp_x); e->mp_y = FMA(e->mp_v, s->dt, e->mp_y);
     if (e->p[2] - s->bottom <= s->mp_top && FABS(e->p[0] - e->mp_x) <= s->mp_hx && FABS(e->p[1] - e->mp_y) <= s->mp_hy) e->flags |= FL_CONTACT;
@@ -1060,7 +1074,7 @@ EXPORT void ORC(attitude_run)(const dql_config* c, const double* quat_xyzw, cons
     quat_to_R(q, R); yaw_cs4(R, &cy, &sy, &ct, &rn);
     det_sincos((REAL)cmd[i * 4 + 1], &sp_, &cp_); det_sincos((REAL)cmd[i * 4 + 0], &sr_, &cr_);
     B[0] = cp_; B[1] = R_(0.0); B[2] = sp_; B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_); B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
-    attitude(&s, R, w, B, cy, sy, ct, rn, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M);
+    attitude(&s, R, w, B, cy, sy, ct, rn, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M, 0);
     for (int k = 0; k < 3; ++k) moment[i * 3 + k] = M[k];
     for (int k = 0; k < 4; ++k) rotor[i * 4 + k] = out[k];
   }
