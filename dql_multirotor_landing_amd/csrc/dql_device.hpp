@@ -146,6 +146,16 @@ template <typename T> DQL_DEV T det_atan(T x) {
   } else if (x < T(2.4375)) { id = 2; x = (x - T(1.5)) / (T(1.0) + T(1.5) * x); hi = T(9.82793723247329054082e-01); lo = T(1.39033110312309984516e-17); }
   else { id = 3; x = T(-1.0) / x; hi = T(1.57079632679489655800e+00); lo = T(6.12323399573676603587e-17); }
   const T z = x * x, w = z * z;
+  if constexpr (sizeof(T) == 4) {
+    // float32 (round 4): the float kernel's five coefficients (fdlibm s_atanf.c) in fused Horner form, 5 instructions instead of the double
+    // kernel's eleven coefficients spelled as 22 separate multiplications and additions; same argument reduction, < 1e-7 absolute
+    const T s1 = z * fma_(w, fma_(w, T(6.1687607318e-02), T(1.4253635705e-01)), T(3.3333328366e-01));
+    const T s2 = w * fma_(w, T(-1.0648017377e-01), T(-1.9999158382e-01));
+    T r;
+    if (id < 0) r = x - x * (s1 + s2);
+    else r = hi - ((x * (s1 + s2) - lo) - x);
+    return neg ? -r : r;
+  }
   const T s1 = z * (T(3.33333333333329318027e-01) + w * (T(1.42857142725034663711e-01) + w * (T(9.09088713343650656196e-02) +
                w * (T(6.66107313738753120669e-02) + w * (T(4.97687799461593236017e-02) + w * T(1.62858201153657823623e-02))))));
   const T s2 = w * (T(-1.99999999998764832476e-01) + w * (T(-1.11111104054623557880e-01) + w * (T(-7.69187620504482999495e-02) +
@@ -182,6 +192,12 @@ template <typename T> DQL_DEV T det_log(T x) {  // x in (0, 1], normal
   const T f = m - T(1.0);
   const T s = f / (T(2.0) + f);
   const T z = s * s, w = z * z;
+  if constexpr (sizeof(T) == 4) {  // float32 (round 4): fdlibm e_logf.c's four coefficients, fused
+    const T t1 = w * fma_(w, T(0.24279078841), T(0.40000972152));
+    const T t2 = z * fma_(w, T(0.28498786688), T(0.66666662693));
+    const T Rr = t2 + t1, hfsq = T(0.5) * f * f, dk = (T)k;
+    return dk * T(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + Rr) + dk * T(1.90821492927058770002e-10))) - f);
+  }
   const T t1 = w * (T(3.999999999940941908e-01) + w * (T(2.222219843214978396e-01) + w * T(1.531383769920937332e-01)));
   const T t2 = z * (T(6.666666666666735130e-01) + w * (T(2.857142874366239149e-01) + w * (T(1.818357216161805012e-01) +
                w * T(1.479819860511658591e-01))));
@@ -579,6 +595,13 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s, T& ct, T&
 // float32 (Fast32): E = R_des^T R with R_des = Rz(yaw) B and R = Rz(yaw) A, A = Ry(pitch) Rx(roll) the yaw-free attitude, is B^T A — and A needs
 // no yaw at all: its last row is R's, A00 = cos(pitch) = sqrt(R00^2 + R10^2) = ct, A10 = 0, sin / cos(roll) = R21 / ct, R22 / ct = R7 rn, R8 rn,
 // sin(pitch) = -R20.  5 multiplications + 19 for the seven entries instead of 2 + 12 (R_des) + 21; cy, sy are only needed by the manager tick.
+// float32 rotor command: sqrt of the allocated w^2 clamped from BOTH sides in one v_med3 — below at 1e-30 (a rotor commanded to stop is commanded
+// to 1e-15 rad/s: sqrt_pos's domain), above at omax^2, which replaces the motor model's min(cmd, omax) (gazebo_motor_model.cpp:358-364): for a
+// correctly rounded, hence monotone, square root and an omax whose square is a float (838^2) min(sqrt(x), omax) == sqrt(min(x, omax^2)) bit for bit.
+// rotor_filter<PRE_CLIPPED> then takes the command as the reference.  One four-cycle instruction per rotor and tick instead of two.
+template <typename K> DQL_DEV float rotor_cmd(const K& s, float w2) {
+  return sqrt_pos(__builtin_amdgcn_fmed3f(w2, SQRT_POS_MIN, (float)s.omax * (float)s.omax));
+}
 // xonly (float32, round 4): an x-axis config flies with a roll set-point of exactly 0, so B = Ry(pitch_sp) = [[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]] and the
 // seven entries collapse: E10 = 0, E12 = -sin(roll), the others lose their middle term — 14 instructions instead of 24, and B is two registers, not nine.
 // Compile-time in the layouts the host selects by itself (k_step's XMODE), a wave-uniform test in the others; the oracle takes the same form.
@@ -600,7 +623,7 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
       const T a = thrust * s.ia;
       const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) cmd[i] = sqrt_pos(w2[i] > SQRT_POS_MIN ? w2[i] : SQRT_POS_MIN);
+      for (int i = 0; i < 4; ++i) cmd[i] = rotor_cmd(s, w2[i]);
       return;
     }
     E01 = fma_(B[0], A01, fma_(B[3], cr, B[6] * R[7]));
@@ -629,7 +652,7 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
     const T a = thrust * s.ia;
     const T w2[4] = {fma_(M2, T(s.ic), fma_(-M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(M0, T(s.ib), a)), fma_(M2, T(s.ic), fma_(M1, T(s.ib), a)), fma_(-M2, T(s.ic), fma_(-M0, T(s.ib), a))};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cmd[i] = sqrt_pos(w2[i] > SQRT_POS_MIN ? w2[i] : SQRT_POS_MIN);  // a rotor commanded to stop is commanded to 1e-15 rad/s
+    for (int i = 0; i < 4; ++i) cmd[i] = rotor_cmd(s, w2[i]);
   } else {
     const T eR0 = T(0.5) * (E21 - E12), eR1 = T(0.5) * (E02 - E20), eR2 = T(0.5) * (E10 - E01);
     const T eW0 = w[0] - r_cmd * E02, eW1 = w[1] - r_cmd * E12, eW2 = w[2] - r_cmd * E22;
@@ -644,10 +667,10 @@ DQL_DEV void attitude(const K& s, const T (&R)[9], const T (&w)[3], const T (&B)
 }
 // gazebo_motor_model.cpp:434-500 + semi-implicit Euler of one rigid body
 // first-order rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364)
-template <typename T, typename K> DQL_DEV void rotor_filter(const K& s, Env<T>& e, const T (&cmd)[4]) {
+template <bool PRE_CLIPPED = false, typename T, typename K> DQL_DEV void rotor_filter(const K& s, Env<T>& e, const T (&cmd)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const T ref = clip3(cmd[i], T(0.0), T(s.omax));  // cmd = sqrt(..) >= +0: min(cmd, omax)
+    const T ref = (PRE_CLIPPED && Fast32<T>::on) ? cmd[i] : clip3(cmd[i], T(0.0), T(s.omax));  // cmd = sqrt(..) >= +0: min(cmd, omax); float32 tick: rotor_cmd() did it
     if constexpr (Fast32<T>::on) {  // om + (1 - a) (ref - om): the same filter, one instruction less
       const T d = ref - e.om[i];
       const T c = d > T(0.0) ? T(s.oup) : T(s.odn);
@@ -708,9 +731,7 @@ template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e,
   e.q[0] = nw * inv; e.q[1] = nx * inv; e.q[2] = ny * inv; e.q[3] = nz * inv;
 }
 // moving_platform.py:87-127
-template <typename T> DQL_DEV void platform_eval(const SimK<T>& s, Env<T>& e) {
-  T sn, cs;
-  det_sincos(e.mp_phase, sn, cs);
+template <typename T> DQL_DEV void platform_set(const SimK<T>& s, Env<T>& e, T sn, T cs) {
   if (s.traj == DQL_TRAJ_EIGHT) {
     e.mp_x = e.mp_r * cs; e.mp_y = e.mp_r * sn * cs;
     e.mp_u = -(e.mp_r * e.mp_w) * sn; e.mp_v = e.mp_r * e.mp_w * (cs * cs - sn * sn);
@@ -719,8 +740,36 @@ template <typename T> DQL_DEV void platform_eval(const SimK<T>& s, Env<T>& e) {
     e.mp_u = e.mp_r * e.mp_w * cs; e.mp_v = T(0.0);
   }
 }
-template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e) {
-  platform_eval(s, e);
+template <typename T> DQL_DEV void platform_eval(const SimK<T>& s, Env<T>& e) {
+  T sn, cs;
+  det_sincos(e.mp_phase, sn, cs);
+  platform_set(s, e, sn, cs);
+}
+// FLOAT32 STEP, ROUND 4: inside one agent period the platform's sine and cosine are evaluated ONCE, at the period's first manager tick, and carried
+// to the following ticks (four or five per period) by the rotation through the constant phase step delta = omega mp_dt — four instructions per
+// manager tick instead of a 45-instruction sincos.  The phase itself advances exactly as before and stays the persistent state: every period
+// starts again from sincos(phase), so the recurrence never runs for more than five steps (a few ulp).  sin / cos of delta: Taylor to delta^5 /
+// delta^6 for delta <= 0.25 rad (1e-8 relative; the reference platform steps 0.008 rad), det_sincos beyond (per lane).
+template <typename T> struct PlatRec { T sn, cs, sd, cd; };
+template <typename T> DQL_DEV void platform_rec_begin(const SimK<T>& s, const Env<T>& e, PlatRec<T>& r) {
+  det_sincos(e.mp_phase, r.sn, r.cs);
+  const T d = e.mp_w * s.mp_dt;
+  if (d > T(0.25) || d < T(-0.25)) det_sincos(d, r.sd, r.cd);
+  else {
+    const T z = d * d;
+    r.sd = d * fma_(z, fma_(z, T(8.33333333333333322e-03), T(-1.66666666666666657e-01)), T(1.0));
+    r.cd = fma_(z, fma_(z, fma_(z, T(-1.38888888888888894e-03), T(4.16666666666666644e-02)), T(-0.5)), T(1.0));
+  }
+}
+// rec: the fused float32 step's per-period sine / cosine carry (null: evaluate sincos(phase) at this tick — float64, and the stand-alone operators)
+template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e, PlatRec<T>* rec = nullptr, bool first_in_period = true) {
+  if (Fast32<T>::on && rec) {
+    if (first_in_period) platform_rec_begin(s, e, *rec);
+    platform_set(s, e, rec->sn, rec->cs);
+    const T sn = rec->sn, cs = rec->cs;
+    rec->sn = fma_(sn, rec->cd, cs * rec->sd);
+    rec->cs = fma_(cs, rec->cd, -(sn * rec->sd));
+  } else platform_eval(s, e);
   T ph = fma_(e.mp_w, s.mp_dt, e.mp_phase);
   if (ph >= T(6.28318530717958623200e+00)) ph -= T(6.28318530717958623200e+00);
   e.mp_phase = ph;
@@ -741,7 +790,7 @@ template <typename T> DQL_DEV void manager_states(const T (&R)[9], T cy, T sy, T
 // pairs each, ~1 300 instructions per period) are never consumed and are not made.  Same values, bit for bit, as drawing every tick.
 template <typename T>
 DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
-                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, bool with_noise = true) {
+                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, bool with_noise = true, PlatRec<T>* rec = nullptr) {
   const T dxw = e.mp_x - e.p[0], dyw = e.mp_y - e.p[1];
   const T dvx = e.mp_u - e.v[0], dvy = e.mp_v - e.v[1];
   const T rpx = fma_(cy, dxw, sy * dyw), rpy = fma_(cy, dyw, -(sy * dxw));
@@ -772,7 +821,7 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
   }
   e.obs_px = opx; e.obs_py = opy; e.obs_vx = ovx; e.obs_vy = ovy; e.obs_ax = ax_; e.obs_ay = ay_;
   if (e.flags & FL_CONTACT) e.flags |= FL_OBS_CONTACT; else e.flags &= ~FL_OBS_CONTACT;
-  platform_update(s, e);
+  platform_update(s, e, rec, mgr_in_step == 0);
 }
 // platform extrapolation between manager ticks + bumper contact test
 template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e) {
@@ -945,8 +994,8 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const f2 ibn = f2{-(float)c.ib, (float)c.ib};
   const f2 w2_02 = pfma(bc2(M2), bc2((float)c.ic), pfma(hi2(M01), ibn, bc2(a)));          // fma(M2, ic, fma(-+M1, ib, a))
   const f2 w2_13 = pfma(bc2(M2), bc2(-(float)c.ic), pfma(lo2(M01), swp2(ibn), bc2(a)));   // fma(-M2, ic, fma(+-M0, ib, a))
-  const f2 cmd02 = f2{sqrt_pos(w2_02.x > SQRT_POS_MIN ? w2_02.x : SQRT_POS_MIN), sqrt_pos(w2_02.y > SQRT_POS_MIN ? w2_02.y : SQRT_POS_MIN)};
-  const f2 cmd13 = f2{sqrt_pos(w2_13.x > SQRT_POS_MIN ? w2_13.x : SQRT_POS_MIN), sqrt_pos(w2_13.y > SQRT_POS_MIN ? w2_13.y : SQRT_POS_MIN)};
+  const f2 cmd02 = f2{rotor_cmd(c, w2_02.x), rotor_cmd(c, w2_02.y)};
+  const f2 cmd13 = f2{rotor_cmd(c, w2_13.x), rotor_cmd(c, w2_13.y)};
   // ---- rotor forces from the CURRENT rotor speeds + rigid body (gazebo_motor_model.cpp:434-500) ----
   const float l = c.l, h = c.h;
   const f2 q02 = s.om02 * s.om02, q13 = s.om13 * s.om13;
@@ -989,9 +1038,7 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   }
   // ---- first-order rotor speed filter (common.h:147-183), speed limit (gazebo_motor_model.cpp:358-364) ----
   {
-    const f2 ref02 = f2{clip3(cmd02.x, 0.0f, (float)c.omax), clip3(cmd02.y, 0.0f, (float)c.omax)};
-    const f2 ref13 = f2{clip3(cmd13.x, 0.0f, (float)c.omax), clip3(cmd13.y, 0.0f, (float)c.omax)};
-    const f2 d02 = ref02 - s.om02, d13 = ref13 - s.om13;
+    const f2 d02 = cmd02 - s.om02, d13 = cmd13 - s.om13;  // rotor_cmd() clamped at omax already
     const f2 c02 = f2{d02.x > 0.0f ? (float)c.oup : (float)c.odn, d02.y > 0.0f ? (float)c.oup : (float)c.odn};
     const f2 c13 = f2{d13.x > 0.0f ? (float)c.oup : (float)c.odn, d13.y > 0.0f ? (float)c.oup : (float)c.odn};
     s.om02 = pfma(c02, d02, s.om02);
@@ -1215,6 +1262,8 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   DQL_PHASE(e, 1);
   T R[9], cy, sy, ct = T(1.0), rn = T(1.0);
   uint32_t mgr_in_step = 0;
+  PlatRec<T> prec;                      // platform sine / cosine carried between the manager ticks of this period (float32: platform_update)
+  prec.sn = prec.cs = prec.sd = prec.cd = T(0.0);
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
   // the period's last manager tick (wave-uniform): the only one whose observation noise is ever read (manager_obs)
@@ -1224,7 +1273,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     DQL_SECTION("manager");
     DQL_PHASE(e, 2);
     manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
-    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
+    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec);
     ++mgr_in_step; ++mgr_index;
     DQL_PHASE(e, 3);
   };
@@ -1237,7 +1286,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     attitude(h, R, e.w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, XMODE == X_ONLY || (XMODE == X_RUNTIME && s.two_axis == 0));
     DQL_SECTION("motor_body");
     plant_step(h, e, R);
-    rotor_filter(h, e, cmd);
+    rotor_filter<true>(h, e, cmd);
     DQL_SECTION("platform_contact");
     platform_contact(h, e);
   };
@@ -1261,7 +1310,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
           float Rm[9];  // scoped: a long-lived array would be demoted to LDS by the compiler
           rot_to_array(rp, Rm);
           manager_states(Rm, rp.cy, rp.sy, e.v[2], e.vz_state, e.yw_state);
-          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr);
+          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec);
           ++mgr_in_step; ++mgr_index;
           DQL_PHASE(e, 3);
         }

@@ -111,6 +111,16 @@ static inline REAL det_atan(REAL x) {
   } else if (x < R_(2.4375)) { id = 2; x = (x - R_(1.5)) / (R_(1.0) + R_(1.5) * x); }
   else { id = 3; x = R_(-1.0) / x; }
   const REAL z = x * x, w = z * z;
+#if ORACLE_F32 /* round 4: the float kernel's five coefficients (fdlibm s_atanf.c), fused Horner form — csrc/dql_device.hpp det_atan */
+  {
+    const REAL s1 = z * FMA(w, FMA(w, 6.1687607318e-02f, 1.4253635705e-01f), 3.3333328366e-01f);
+    const REAL s2 = w * FMA(w, -1.0648017377e-01f, -1.9999158382e-01f);
+    REAL r;
+    if (id < 0) r = x - x * (s1 + s2);
+    else r = R_(hi[id]) - ((x * (s1 + s2) - R_(lo[id])) - x);
+    return neg ? -r : r;
+  }
+#endif
   const REAL s1 = z * (R_(3.33333333333329318027e-01) + w * (R_(1.42857142725034663711e-01) + w * (R_(9.09088713343650656196e-02) +
                   w * (R_(6.66107313738753120669e-02) + w * (R_(4.97687799461593236017e-02) + w * R_(1.62858201153657823623e-02))))));
   const REAL s2 = w * (R_(-1.99999999998764832476e-01) + w * (R_(-1.11111104054623557880e-01) + w * (R_(-7.69187620504482999495e-02) +
@@ -147,6 +157,14 @@ static inline REAL det_log(REAL x) {
   const REAL f = m - R_(1.0);
   const REAL s = f / (R_(2.0) + f);
   const REAL z = s * s, w = z * z;
+#if ORACLE_F32 /* round 4: fdlibm e_logf.c's four coefficients, fused — csrc/dql_device.hpp det_log */
+  {
+    const REAL t1 = w * FMA(w, 0.24279078841f, 0.40000972152f);
+    const REAL t2 = z * FMA(w, 0.28498786688f, 0.66666662693f);
+    const REAL Rr = t2 + t1, hfsq = R_(0.5) * f * f, dk = (REAL)k;
+    return dk * R_(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + Rr) + dk * R_(1.90821492927058770002e-10))) - f);
+  }
+#endif
   const REAL t1 = w * (R_(3.999999999940941908e-01) + w * (R_(2.222219843214978396e-01) + w * R_(1.531383769920937332e-01)));
   const REAL t2 = z * (R_(6.666666666666735130e-01) + w * (R_(2.857142874366239149e-01) + w * (R_(1.818357216161805012e-01) +
                   w * R_(1.479819860511658591e-01))));
@@ -627,14 +645,16 @@ static inline void attitude(const simc_t* s, const REAL R[9], const REAL w[3], c
   const REAL w2[4] = {a - by + cz, a + bx - cz, a + by + cz, a - bx - cz};
 #endif
 #if ORACLE_F32 /* the kernel's sqrt_pos is the correctly rounded sqrt for x >= 2^-102 (exhaustively verified, dql_device.hpp): a stopped rotor is commanded 1e-15 rad/s */
-  for (int i = 0; i < 4; ++i) cmd[i] = SQRT(w2[i] > 1e-30f ? w2[i] : 1e-30f);
+  /* round 4: both clamps in one v_med3 — the upper one, at omax^2, replaces the motor model's min(cmd, omax) (exact for a correctly rounded sqrt and
+   * an omax whose square is a float); motor_and_body(pre_clipped) then takes the command as the reference */
+  for (int i = 0; i < 4; ++i) cmd[i] = SQRT(clip3(w2[i], 1e-30f, s->omax * s->omax));
 #else
   for (int i = 0; i < 4; ++i) cmd[i] = SQRT(w2[i] > R_(0.0) ? w2[i] : R_(0.0));
 #endif
 }
 
 /* gazebo_motor_model.cpp:434-500 (forces from the CURRENT rotor speeds) + one semi-implicit Euler step of the body */
-static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], const REAL cmd[4]) {
+static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], const REAL cmd[4], int pre_clipped) {
   const REAL* om = e->om; const REAL* w = e->w; const REAL l = s->l, h = s->h;
   /* thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
    * (gazebo_motor_model.cpp:441-452, 476-482; allocation signs pkg/attitude_controller.py:98-104) */
@@ -654,7 +674,12 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   tx = FMA(s->crd, Fbx, tx); ty = FMA(s->crd, Fby, ty);
   /* rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364) */
   for (int i = 0; i < 4; ++i) {
+#if ORACLE_F32
+    const REAL ref = pre_clipped ? cmd[i] : clip3(cmd[i], R_(0.0), s->omax);
+#else
+    (void)pre_clipped;
     const REAL ref = clip3(cmd[i], R_(0.0), s->omax);  /* cmd = sqrt(..) >= +0: min(cmd, omax) */
+#endif
 #if ORACLE_F32 /* om + (1 - a)(ref - om): the same filter, one operation less */
     const REAL d = ref - e->om[i];
     const REAL c = d > R_(0.0) ? s->oup : s->odn;
@@ -699,9 +724,29 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
 }
 
 /* pkg/moving_platform.py:87-127, phase = omega * t kept wrapped in [0, 2 pi) */
-static inline void platform_update(const simc_t* s, env_t* e) {
+/* rec (float32 fused step, round 4; csrc/dql_device.hpp platform_update): sine / cosine evaluated at the period's first manager tick and carried to
+ * its other ticks by the rotation through the constant phase step delta = omega mp_dt; NULL = evaluate at this tick */
+typedef struct { REAL sn, cs, sd, cd; } platrec_t;
+static inline void platform_update(const simc_t* s, env_t* e, platrec_t* rec, int first_in_period) {
   REAL sn, cs;
-  det_sincos(e->mp_phase, &sn, &cs);
+#if ORACLE_F32
+  if (rec) {
+    if (first_in_period) {
+      det_sincos(e->mp_phase, &rec->sn, &rec->cs);
+      const REAL d = e->mp_w * s->mp_dt;
+      if (d > R_(0.25) || d < R_(-0.25)) det_sincos(d, &rec->sd, &rec->cd);
+      else {
+        const REAL z = d * d;
+        rec->sd = d * FMA(z, FMA(z, R_(8.33333333333333322e-03), R_(-1.66666666666666657e-01)), R_(1.0));
+        rec->cd = FMA(z, FMA(z, FMA(z, R_(-1.38888888888888894e-03), R_(4.16666666666666644e-02)), R_(-0.5)), R_(1.0));
+      }
+    }
+    sn = rec->sn; cs = rec->cs;
+    rec->sn = FMA(sn, rec->cd, cs * rec->sd);
+    rec->cs = FMA(cs, rec->cd, -(sn * rec->sd));
+  } else
+#endif
+  { (void)rec; (void)first_in_period; det_sincos(e->mp_phase, &sn, &cs); }
   if (s->traj == DQL_TRAJ_EIGHT) {
     e->mp_x = e->mp_r * cs; e->mp_y = e->mp_r * sn * cs;
     e->mp_u = -(e->mp_r * e->mp_w) * sn; e->mp_v = e->mp_r * e->mp_w * (cs * cs - sn * sn);
@@ -724,7 +769,7 @@ static inline void platform_update(const simc_t* s, env_t* e) {
 static int g_eager_noise = 0;
 EXPORT void ORC(set_eager_noise)(int on) { g_eager_noise = on; }
 static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL cy, REAL sy, int64_t mgr_index,
-                                uint32_t k0, uint32_t k1, uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, int with_noise) {
+                                uint32_t k0, uint32_t k1, uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, int with_noise, platrec_t* rec) {
   const REAL dxw = e->mp_x - e->p[0], dyw = e->mp_y - e->p[1];
   const REAL dvx = e->mp_u - e->v[0], dvy = e->mp_v - e->v[1];
   const REAL rpx = FMA(cy, dxw, sy * dyw), rpy = FMA(cy, dyw, -(sy * dxw));
@@ -767,7 +812,7 @@ static inline void manager_tick(const simc_t* s, env_t* e, const REAL R[9], REAL
   e->obs[0] = opx; e->obs[1] = opy; e->obs[2] = ovx; e->obs[3] = ovy; e->obs[4] = ax_; e->obs[5] = ay_;
   /* Observation.contact = the latched bumper flag at publish time (pkg/observation_utils.py:156) */
   if (e->flags & FL_CONTACT) e->flags |= FL_OBS_CONTACT; else e->flags &= ~FL_OBS_CONTACT;
-  platform_update(s, e);
+  platform_update(s, e, rec, mgr_in_step == 0);
 }
 
 /* drone start coordinate along one axis from the random offset x0 and the platform coordinate (init_mode = cfg.init_uniform):
@@ -842,17 +887,18 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
   REAL R[9], cy, sy, ct, rn;
   uint32_t mgr_in_step = 0;
+  platrec_t prec = {R_(0.0), R_(0.0), R_(0.0), R_(0.0)};
   const int phase0 = (int)(g0 % s->div), first_mgr = phase0 ? s->div - phase0 : 0;
   const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s->div) : 0u; /* the period's last manager tick */
   for (int i = 0; i < n_ticks; ++i) {
     const int64_t g = g0 + i;
     quat_to_R(e->q, R); yaw_cs4(R, &cy, &sy, &ct, &rn);
-    if (g % s->div == 0) { manager_tick(s, e, R, cy, sy, g / s->div, k0, k1, step_lo, step_hi, env_id, mgr_in_step, g_eager_noise || mgr_in_step == last_mgr); ++mgr_in_step; }
+    if (g % s->div == 0) { manager_tick(s, e, R, cy, sy, g / s->div, k0, k1, step_lo, step_hi, env_id, mgr_in_step, g_eager_noise || mgr_in_step == last_mgr, &prec); ++mgr_in_step; }
     const REAL thrust = pid_output(&s->pvz, &s->bw, &e->vz, s->dt);
     const REAL r_cmd = pid_output(&s->pyaw, &s->bw, &e->yaw, s->dt);
     REAL cmd[4], M[3];
     attitude(s, R, e->w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, M, !s->two_axis);
-    motor_and_body(s, e, R, cmd);
+    motor_and_body(s, e, R, cmd, 1);
     e->mp_x = FMA(e->mp_u, s->dt, e->mp_x); e->mp_y = FMA(e->mp_v, s->dt, e->mp_y);
     if (e->p[2] - s->bottom <= s->mp_top && FABS(e->p[0] - e->mp_x) <= s->mp_hx && FABS(e->p[1] - e->mp_y) <= s->mp_hy) e->flags |= FL_CONTACT;
   }
@@ -1084,7 +1130,7 @@ EXPORT void ORC(platform_run)(const dql_config* c, int64_t n, double* out) {
   simc_t s; simc_init(&s, c);
   env_t e; memset(&e, 0, sizeof(e));
   e.mp_r = s.mp_r; e.mp_w = s.mp_w;
-  for (int64_t i = 0; i < n; ++i) { platform_update(&s, &e); out[i * 4] = e.mp_x; out[i * 4 + 1] = e.mp_y; out[i * 4 + 2] = e.mp_u; out[i * 4 + 3] = e.mp_v; }
+  for (int64_t i = 0; i < n; ++i) { platform_update(&s, &e, NULL, 1); out[i * 4] = e.mp_x; out[i * 4 + 1] = e.mp_y; out[i * 4 + 2] = e.mp_u; out[i * 4 + 3] = e.mp_v; }
 }
 /* the 100 Hz manager tick (scripts/manager_node.py:192-214,292-310 + pkg/observation_utils.py:77-158) replayed over a scripted
  * series: per tick in[14] = drone p(3), v(3), quaternion w x y z (world frame), platform x y u v as Gazebo reports them at this
@@ -1105,7 +1151,7 @@ EXPORT void ORC(manager_run)(const dql_config* c, int64_t n_ticks, const double*
     if (contact[t]) e.flags |= FL_CONTACT;
     REAL R[9], cy, sy;
     quat_to_R(e.q, R); yaw_cs(R, &cy, &sy);
-    manager_tick(&s, &e, R, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, 0u, (uint32_t)t, 1);
+    manager_tick(&s, &e, R, cy, sy, t, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u, 0u, (uint32_t)t, 1, NULL);
     double* o = out + t * 12;
     o[0] = e.obs[0]; o[1] = e.obs[1]; o[2] = e.obs[2]; o[3] = e.obs[3]; o[4] = e.obs[4]; o[5] = e.obs[5];
     o[6] = e.vz.state; o[7] = e.yaw.state; o[8] = e.mp_x; o[9] = e.mp_y; o[10] = e.mp_u; o[11] = e.mp_v;
@@ -1124,7 +1170,7 @@ EXPORT void ORC(plant_run)(const dql_config* c, int64_t n_ticks, const double* i
     const REAL cmd[4] = {(REAL)cmd_in[t * 4], (REAL)cmd_in[t * 4 + 1], (REAL)cmd_in[t * 4 + 2], (REAL)cmd_in[t * 4 + 3]};
     REAL R[9];
     quat_to_R(e.q, R);
-    motor_and_body(&s, &e, R, cmd);
+    motor_and_body(&s, &e, R, cmd, 0);
     e.mp_x = FMA(e.mp_u, s.dt, e.mp_x); e.mp_y = FMA(e.mp_v, s.dt, e.mp_y);
     if (e.p[2] - s.bottom <= s.mp_top && FABS(e.p[0] - e.mp_x) <= s.mp_hx && FABS(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
     double* o = out + t * 20;
