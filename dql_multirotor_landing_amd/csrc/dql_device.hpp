@@ -211,8 +211,9 @@ template <typename T> DQL_DEV T det_log(T x) {  // x in (0, 1], normal
 DQL_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: integer multiplies are quarter rate
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -261,6 +262,7 @@ template <typename T> struct SimK {
   T bw_b2, bw_a2, bw_a3;  // float32 tick (round 4): transposed Butterworth, 2 / denom, k2 / denom, k1 / denom
   T mp_dt, mp_top, mp_hx, mp_hy, bottom;
   T noise_p, noise_v, kal_q, kal_r, mgr_dt, mp_r, mp_w;
+  T kal_pss, kal_kss;  // the Kalman covariance's fixed point in T arithmetic and its gain (host: kalman_fixed_point), NaN = none
   T p_max, theta_max, delta_theta, z_init, init_sigma;  // reset placement / set-point update (before the loop)
   int div, traj, init_uniform, working, per_env_platform, two_axis;
   uint32_t quirks;
@@ -525,7 +527,16 @@ DQL_DEV T pid_output(const K& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, 
   if constexpr (Fast32<T>::on) return clip3(fma_(kp, fe, ki * integ), lo, hi);
   else return clip3(kp * fe + ki * integ, lo, hi);
 }
-template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z) {  // filters.py:19-36
+// pss / kss: P's fixed point under this very update in T arithmetic, and the gain there (make_simk iterates the same three operations on the
+// host).  The covariance does not depend on the data and is never reset (B15): a second of simulated time after an engine's creation every
+// env sits ON the fixed point, bit for bit, and the update would recompute the same K and the same P at every 100 Hz tick — two additions, a
+// correctly rounded division (ten instructions), a subtraction and a multiplication.  When every lane of the wave is there they are skipped:
+// the same values by construction, so the oracle keeps the plain update.
+template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z, T pss = T(-1.0), T kss = T(0.0)) {  // filters.py:19-36
+  if (__ballot(!(P == pss)) == 0ull) {
+    x += kss * (z - x);
+    return x;
+  }
   P += Q;
   if (Rm == T(0.0)) {  // wave-uniform (launch files: no measurement noise): P / (P + 0) is exactly 1, no division to pay for
     x += (z - x);
@@ -811,11 +822,11 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
     else dt_ = s.mgr_dt;
     if (dt_ <= T(0.0)) dt_ = T(0.01);
     if (Fast32<T>::on && !(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) {  // constant divisor: one multiplication (float32 tick)
-      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) * s.inv_mgr_dt);
-      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) * s.inv_mgr_dt);
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) * s.inv_mgr_dt, s.kal_pss, s.kal_kss);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) * s.inv_mgr_dt, s.kal_pss, s.kal_kss);
     } else {
-      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_);
-      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_);
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_, s.kal_pss, s.kal_kss);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_, s.kal_pss, s.kal_kss);
     }
     if (!(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e.vf_x = rvx; if (s.two_axis) e.vf_y = rvy; }
   }

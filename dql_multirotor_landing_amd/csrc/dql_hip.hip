@@ -13,6 +13,7 @@
 //   k_apply_window           multi-GPU: folds the all-reduced window accumulators into the base tables.
 //   small stateless kernels  drop-in single-call operators (discretise, mdp transition, predict, ordered update).
 #include <hip/hip_runtime.h>
+#include <limits>
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed on first use (dql_comm_*)
 
 #include <dlfcn.h>
@@ -74,6 +75,25 @@ static bool refk_matches(const SimK<float>& s) {
 #undef DQL_A
   return ok;
 }
+// P's fixed point under kalman1d's update in T arithmetic (P += Q; K = P / (P + R); P *= 1 - K), reached from the creation value P = 1; pss = NaN when
+// the iteration does not settle on one value (then the kernel's shortcut never fires).  R = 0: kalman1d's own shortcut applies, no fixed point needed.
+template <typename T> static void kalman_fixed_point(T Q, T R, T& pss, T& kss) {
+  static thread_local T memo_q = T(-1), memo_r = T(-1), memo_p = T(0), memo_k = T(0);  // make_simk runs once per launch: remember the last answer
+  if (Q == memo_q && R == memo_r) { pss = memo_p; kss = memo_k; return; }
+  pss = std::numeric_limits<T>::quiet_NaN(); kss = T(0);
+  memo_q = Q; memo_r = R; memo_p = pss; memo_k = kss;
+  if (!(R > T(0)) || !(Q >= T(0))) return;
+  volatile T P = T(1);
+  for (int i = 0; i < 200000; ++i) {
+    volatile T P1 = P + Q;
+    volatile T den = P1 + R;
+    volatile T K = P1 / den;
+    volatile T om = T(1) - K;
+    volatile T P2 = P1 * om;
+    if (P2 == P) { pss = P; kss = K; memo_p = pss; memo_k = kss; return; }
+    P = P2;
+  }
+}
 template <typename T> static SimK<T> make_simk(const dql_config& c) {
   SimK<T> d;
   memset(&d, 0, sizeof(d));
@@ -93,6 +113,7 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   d.mp_dt = (T)c.mp_dt; d.mp_top = (T)c.mp_top_z; d.mp_hx = (T)c.mp_half_x; d.mp_hy = (T)c.mp_half_y; d.bottom = (T)c.drone_bottom;
   d.noise_p = (T)c.noise_pos_sd; d.noise_v = (T)c.noise_vel_sd; d.kal_q = (T)c.kalman_q; d.kal_r = (T)(c.noise_vel_sd * c.noise_vel_sd);
   d.mgr_dt = (T)(c.dt * c.manager_div);
+  kalman_fixed_point<T>(d.kal_q, d.kal_r, d.kal_pss, d.kal_kss);
   d.mp_r = (T)c.mp_r_x; d.mp_w = (T)(c.mp_t_x / c.mp_r_x);
   if (c.trajectory == DQL_TRAJ_EIGHT) { d.mp_r = (T)3.0; d.mp_w = (T)(0.8 / 3.0); }
   d.p_max = (T)c.p_max; d.theta_max = (T)c.theta_max; d.delta_theta = (T)c.delta_theta; d.z_init = (T)c.z_init; d.init_sigma = (T)c.init_sigma;
@@ -1166,8 +1187,19 @@ int dql_step(dql_ctx* x, const uint8_t* actions) {
     else HIP_TRY(hipEventSynchronize(x->ev_actions));
     x->actions_in_flight = false;
   }
-  memcpy(x->h_actions, actions, (size_t)x->n);
   x->actions_zero_copy = x->n <= DQL_ZERO_COPY_ENVS;
+  if (x->actions_zero_copy) {
+    // small batches (the single-env drop-in path among them): the bytes are being touched anyway, so the action codes are checked HERE and a bad
+    // one is refused before anything is flown — the reject-before-mutation contract of the old host loop.  Larger batches are checked by the
+    // step kernel (per env, StatsDev::bad_actions) and reported by the next dql_step_outputs / dql_stats_get: see include/dql.h.
+    const bool two = x->cfg.two_axis != 0;
+    for (long long i = 0; i < x->n; ++i) {
+      const unsigned a = actions[i], ax = a & 3u, ay = (a >> 2) & 3u;
+      if (ax > 2u || ay > 2u || (a >> 4) || (!two && ay != 0u && ay != 2u))
+        return fail(DQL_EINVAL, "action " + std::to_string(a) + " of env " + std::to_string(i) + " is out of range: ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold); ay only in two_axis configs");
+      x->h_actions[i] = (uint8_t)a;
+    }
+  } else memcpy(x->h_actions, actions, (size_t)x->n);
   if (x->actions_zero_copy) {
     x->ext_actions = (const uint8_t*)x->h_actions_dev;
   } else {

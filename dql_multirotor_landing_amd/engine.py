@@ -52,8 +52,10 @@ class Engine:
         a = np.ascontiguousarray(actions, dtype=np.uint8)
         if a.shape != (self.n,):
             raise ValueError(f"actions must have shape ({self.n},)")
-        if (a > 10).any() or ((a & 3) > 2).any():  # ax | ay << 2 with ax, ay in 0..2: at most 2 | 2 << 2 = 10 (the kernel checks again, per env)
+        if (a > 10).any() or ((a & 3) > 2).any():  # ax | ay << 2 with ax, ay in 0..2: at most 2 | 2 << 2 = 10 (the library checks again)
             raise ValueError("actions must be ax | ay << 2 with ax, ay in 0 (increase), 1 (decrease), 2 (hold)")
+        if not self.cfg.two_axis and ((a >> 2) % 2 != 0).any():  # ay in {0 (not given), 2 (hold)}: pkg/mdp.py:544-545 raises for anything else
+            raise ValueError("Cannot move in the y direction while training")
         _lib.check(self.lib.dql_step(self._h, _p(a)))
 
     def step_raw(self, a):

@@ -165,8 +165,11 @@ int dql_set_curriculum(dql_ctx* ctx, int32_t working_curriculum_step);
  * is executed by the next step/train call, as the reference's reset() runs one agent period of simulation */
 int dql_reset(dql_ctx* ctx, const uint8_t* mask_or_null);
 /* one agent step with caller-supplied actions (uint8 per env: ax | ay << 2, ax, ay in 0 / 1 / 2, ay only in two_axis configs); no table
- * update.  The actions are staged through pinned host memory and checked BY THE KERNEL (no host loop over n_envs, no wait): an
- * out-of-range action is flown as "hold" and makes the next dql_step_outputs / dql_stats_get return DQL_EINVAL once. */
+ * update.  The actions are staged through pinned host memory.  Up to 16 384 envs (the single-env drop-in path among them) the codes are
+ * checked while they are staged and a bad one is REFUSED before anything is flown: DQL_EINVAL, no env has moved (the reference raises before
+ * publishing the action, pkg/mdp.py:544-545).  Beyond that the step kernel checks them per env (no host loop over n_envs, no wait): an
+ * out-of-range action is flown as "hold" and makes the next dql_step_outputs / dql_stats_get return DQL_EINVAL once — a caller that reads
+ * results with dql_get_states / dql_get_sim_state only must ask dql_stats_get for the verdict. */
 int dql_step(dql_ctx* ctx, const uint8_t* actions);
 /* what `TrainingLandingEnv.step` returns (pkg/landing_simulation_env.py:245-282), for every env, in ONE device round trip: packed
  * states, reward, done ("Termination condition" in info), CheckResult code, "Number of steps", cumulative reward (after this step's

@@ -176,8 +176,8 @@ def test_resident_agent_equals_stateless_operators(ops):
 @pytest.mark.parametrize("n", [200, 300, 20000])
 def test_step_outputs_and_kernel_side_action_check(n):
     """dql_step_outputs == what the field getters say (state, reward, done, code, step count, cumulative reward, reset flag) in one round
-    trip; an out-of-range action handed straight to the C ABI is flown as "hold" and reported ONCE by the next outputs / stats call —
-    the host no longer loops over the actions.  The three sizes take the three paths of the pair dql_step / dql_step_outputs: 200 — one
+    trip; an out-of-range action handed straight to the C ABI is refused before anything moves (up to 16 384 envs) or flown as "hold" and reported
+    ONCE by the next outputs / stats call (beyond: no host loop over the actions).  The three sizes take the three paths of the pair dql_step / dql_step_outputs: 200 — one
     workgroup: actions read from pinned memory by the step kernel, results picked up when the kernel posts its sequence number; 300 —
     several workgroups: the stream is waited for; 20 000 (> DQL_ZERO_COPY_ENVS) — actions copied to the device first."""
     import ctypes as C
@@ -201,13 +201,25 @@ def test_step_outputs_and_kernel_side_action_check(n):
         np.testing.assert_array_equal(o["step_count"], ints[im.index("step_count")])
     assert o["done"].sum() + o["was_reset"].sum() > 0
     bad = np.full(n, 2, dtype=np.uint8); bad[7] = 3; bad[9] = 1 << 2      # ax = 3; a y action in an x-axis config
-    assert eng.lib.dql_step(eng._h, bad.ctypes.data_as(C.c_void_p)) == 0  # accepted: nobody loops over n_envs on the host
-    with pytest.raises(ValueError, match="2 action"):
-        eng.step_outputs()
-    eng.step_outputs()                                                   # reported once
-    hold = np.full(n, 2, dtype=np.uint8); hold[9] = 0
-    twin.step(hold)                                                      # ax = 3 flew as "hold"; env 9's x action (0) was flown, its y action had nothing to act on
-    np.testing.assert_array_equal(eng.get_fields()[0], twin.get_fields()[0])
+    if n <= 16384:
+        # small batches (the single-env drop-in path among them) are checked while the actions are staged: refused BEFORE anything is flown
+        before = eng.get_fields()
+        assert eng.lib.dql_step(eng._h, bad.ctypes.data_as(C.c_void_p)) == _lib.EINVAL
+        after = eng.get_fields()
+        np.testing.assert_array_equal(before[0], after[0]); np.testing.assert_array_equal(before[1], after[1])
+        only_y = np.full(n, 2, dtype=np.uint8); only_y[9] = 1 << 2
+        assert eng.lib.dql_step(eng._h, only_y.ctypes.data_as(C.c_void_p)) == _lib.EINVAL   # "Cannot move in the y direction while training"
+        eng.step_outputs()                                                # nothing pending: no error is reported later either
+    else:
+        assert eng.lib.dql_step(eng._h, bad.ctypes.data_as(C.c_void_p)) == 0  # accepted: nobody loops over 20 000 envs on the host
+        with pytest.raises(ValueError, match="2 action"):
+            eng.step_outputs()
+        eng.step_outputs()                                                   # reported once
+        hold = np.full(n, 2, dtype=np.uint8); hold[9] = 0
+        twin.step(hold)                                                      # ax = 3 flew as "hold"; env 9's x action (0) was flown, its y action had nothing to act on
+        np.testing.assert_array_equal(eng.get_fields()[0], twin.get_fields()[0])
+    with pytest.raises(ValueError, match="y direction"):
+        eng.step(np.full(n, 2 | 1 << 2, dtype=np.uint8))                 # Engine.step: a y action in an x-axis config, as the reference raises
     with pytest.raises(ValueError):
         eng.step(np.full(n, 3, dtype=np.uint8))                          # the Python layer still refuses up front, as the reference's step() raises
     eng.close(); twin.close()
