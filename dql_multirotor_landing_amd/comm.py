@@ -10,9 +10,12 @@ All ranks of a node share their parent (torch.distributed.run's agent, or `bench
 time) of a live process is unique, so a file left behind by an earlier job can never be mistaken for this one's; `<n>`
 counts the communicators a process has created (every rank creates them in the same order).  Rank 0 writes the file
 atomically (temp + rename) and removes it when the communicator is closed.  An explicit $DQL_COMM_ID_FILE has no such nonce
-in its name, so every bootstrap file also carries one inside — a 16-byte header (magic, MASTER_PORT, WORLD_SIZE) — and a reader
-only accepts a file with its own job's header that is not older than the reader itself (minus a minute of slack for ranks that
-start late): what a killed job left behind is polled past, not used.
+in its name, so every bootstrap file also carries one INSIDE: a 24-byte header (magic, MASTER_PORT, WORLD_SIZE, 12 bytes of job nonce).
+The nonce is a hash of $DQL_COMM_JOB_ID when the launcher sets one (ranks that do not share a parent: mpirun, srun), else of
+$TORCHELASTIC_RUN_ID + the parent's (pid, start time) — the same for every rank of a job, different for any other job, whenever it runs.
+A reader accepts a file with its own job's header only: what a killed job left behind — even one relaunched seconds later on the same
+port — is polled past, however old or young it is, and a rank that starts minutes after rank 0 still finds rank 0's file valid.
+Rank 0 removes whatever sits under the name before it creates its communicator.
 
 Launch contract (same variables torch.distributed.run exports): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.
 """
@@ -32,20 +35,24 @@ from . import _lib
 
 _created = 0          # communicators created by this process so far
 _env_comm = None      # the job's communicator (from_env), shared by everything in this process
-_T_START = time.time()  # this process's start, near enough: bootstrap files older than this (minus _STALE_SLACK_S) are leftovers
-_STALE_SLACK_S = 60.0
+
+
+def _job_nonce() -> bytes:
+    """12 bytes every rank of THIS job computes alike and no other job does (module docstring)"""
+    import hashlib
+    job = os.environ.get("DQL_COMM_JOB_ID")
+    key = f"job:{job}" if job else f"run:{os.environ.get('TORCHELASTIC_RUN_ID', '')}|parent:{_parent_token()}"
+    return hashlib.sha256(key.encode()).digest()[:12]
 
 
 def _header(world: int) -> bytes:
     port = int(os.environ.get("MASTER_PORT", "0") or 0) & 0xFFFFFFFF
-    return b"DQLC" + port.to_bytes(4, "little") + int(world).to_bytes(4, "little") + b"\0\0\0\0"
+    return b"DQLD" + port.to_bytes(4, "little") + int(world).to_bytes(4, "little") + _job_nonce()
 
 
 def _read_fresh(f: Path, world: int, n_payload: int) -> Optional[bytes]:
-    """payload of bootstrap file `f` if it is this job's (header) and not a leftover (age), else None"""
+    """payload of bootstrap file `f` if it is this job's (header with the job nonce), else None"""
     try:
-        if f.stat().st_mtime < _T_START - _STALE_SLACK_S:
-            return None
         b = f.read_bytes()
     except OSError:
         return None
@@ -135,6 +142,10 @@ class RcclComm:
         self._id_file = id_file_path(seq)
         uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
         if self.rank == 0:
+            try:  # whatever an earlier job left under this name goes before this job's id exists
+                self._id_file.unlink()
+            except OSError:
+                pass
             _lib.check(self.lib.dql_comm_unique_id(uid))
             if self.world > 1:
                 tmp = self._id_file.with_suffix(f".{os.getpid()}.tmp")

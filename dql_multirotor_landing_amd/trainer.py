@@ -234,6 +234,11 @@ class Trainer:
         self._save_path.mkdir(parents=True, exist_ok=True)
         self._double_q_learning_agent.save(self._save_path)
         self._double_q_learning_agent.save(self._save_path / "..")
+        # the three .npy files keep the reference's layout, so the checkpoint they belong to is named NEXT to them: a run killed between the
+        # tables and trainer.json leaves newer tables under the older progress counters, and load() says so
+        tmp = self._save_path / f".tables.tag.json.{os.getpid()}.tmp"
+        tmp.write_text(json.dumps(tag))
+        os.replace(tmp, self._save_path / "tables.tag.json")
         st = self._state_dict()
         if st["progress"] is not None:
             st["progress"] = dict(st["progress"], tag=tag)
@@ -259,6 +264,14 @@ class Trainer:
         with open(run / "trainer.json") as f:
             st = json.load(f)
         agent = DoubleQLearningAgent.load(run)
+        try:
+            tables_tag = json.loads((run / "tables.tag.json").read_text())
+        except (OSError, ValueError):
+            tables_tag = None
+        want_tag = (st.get("progress") or {}).get("tag")
+        if tables_tag is not None and want_tag is not None and tables_tag != want_tag:
+            warnings.warn(f"the tables in {run.name} belong to checkpoint {tables_tag}, trainer.json to {want_tag}: the run was stopped between the two "
+                          "writes — resuming with the newer tables under the older progress and episode counters", RuntimeWarning)
         build = dict(st.get("build", {"n_envs": st.get("n_envs", 4096), "mode": st.get("mode", "reference")}))
         build.update(kw)
         tr = Trainer(curriculum_steps=st["curriculum_steps"], double_q_learning_agent=agent, initial_curriculum_step=st["working_curriculum_step"],
@@ -368,17 +381,24 @@ class Trainer:
             warnings.warn(f"{f.name} belongs to checkpoint {have or 'without a tag'}, trainer.json to {want}: resuming level {progress.get('level')} "
                           "from its tables without the saved simulator state", RuntimeWarning)
             return None
-        if z["ints"].shape[1] != eng.n:
-            raise ValueError(f"{f} holds {z['ints'].shape[1]} envs, this rank's shard has {eng.n}")
+        if z["ints"].shape[1] != eng.n:  # raised by _restore_env_state on EVERY rank, after the vote (a lone raise here would leave the others in the collective)
+            self._env_state_error = f"{f} holds {z['ints'].shape[1]} envs, this rank's shard has {eng.n}"
+            return None
         return z
 
     def _restore_env_state(self, eng, progress):
         """Simulator state of the envs from the checkpoint `progress` belongs to — on every rank, or on none (then the level's envs
         start over, its bookkeeping does not)."""
+        self._env_state_error = None
         z = self._load_env_state(eng, progress)
-        ok = z is not None
+        ok, bad = z is not None, self._env_state_error is not None
         if self._comm is not None and self._world > 1:
-            ok = bool(self._comm.all_reduce_sum([0.0 if ok else 1.0])[0] == 0.0)
+            votes = self._comm.all_reduce_sum([0.0 if ok else 1.0, 1.0 if bad else 0.0])
+            ok, bad_anywhere = bool(votes[0] == 0.0), bool(votes[1] > 0.0)
+        else:
+            bad_anywhere = bad
+        if bad_anywhere:  # a shard of another env count is a configuration error, not a missing file: every rank stops, together
+            raise ValueError(self._env_state_error or "another rank's env-state shard holds a different env count than its engine (see that rank's message)")
         if not ok:
             return False
         eng.set_fields(z["reals"].astype(np.float64), z["ints"])

@@ -90,31 +90,47 @@ def test_gather_via_files_two_ranks(tmp_path, monkeypatch):
 
 
 def test_bootstrap_files_of_a_killed_job_are_polled_past(tmp_path, monkeypatch):
-    """with an explicit DQL_COMM_ID_FILE the name carries no job nonce.  Leftovers of a killed job — an old file, a file
-    of another job (other MASTER_PORT / world size), a stray `.done` marker — must not be taken for this job's."""
+    """with an explicit DQL_COMM_ID_FILE the name carries no job nonce, so the header does: a hash of DQL_COMM_JOB_ID, or of
+    TORCHELASTIC_RUN_ID + the parent's (pid, start time).  Leftovers of a killed job — a file of another job (other nonce, MASTER_PORT or world
+    size), however recent, a stray `.done` marker — must not be taken for this job's; and a valid file stays valid however OLD it is (a rank
+    that starts minutes after rank 0 wrote it)."""
     import threading
     import time
     from dql_multirotor_landing_amd import comm
     monkeypatch.setenv("DQL_COMM_ID_FILE", str(tmp_path / "boot.id"))
     monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setenv("DQL_COMM_JOB_ID", "job-A")
     f = tmp_path / "stale.bin"
     f.write_bytes(comm._header(2) + b"x" * 64)
     assert comm._read_fresh(f, 2, 64) == b"x" * 64
     assert comm._read_fresh(f, 3, 64) is None                     # another world size
     old = time.time() - 3600
     os.utime(f, (old, old))
-    assert comm._read_fresh(f, 2, 64) is None                     # older than this process: a leftover
+    assert comm._read_fresh(f, 2, 64) == b"x" * 64                # an hour old and still this job's: a late rank is not locked out
+    monkeypatch.setenv("DQL_COMM_JOB_ID", "job-B")
+    assert comm._read_fresh(f, 2, 64) is None                     # the same file seen by ANOTHER job (relaunch on the same port and world size)
+    f.write_bytes(comm._header(2) + b"x" * 64)                    # ... written by job B a moment ago
+    monkeypatch.setenv("DQL_COMM_JOB_ID", "job-A")
+    assert comm._read_fresh(f, 2, 64) is None                     # fresh, same port, same world: still not job A's
+    monkeypatch.delenv("DQL_COMM_JOB_ID")
+    h1 = comm._header(2)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-7")
+    assert comm._header(2) != h1 and len(h1) == 24               # without a job id: the run id and the parent's (pid, start time) make the nonce
+    monkeypatch.setattr(comm, "_parent_token", lambda: "1_1")
+    assert comm._header(2) != h1
+    monkeypatch.undo()
+    monkeypatch.setenv("DQL_COMM_ID_FILE", str(tmp_path / "boot.id"))
     monkeypatch.setenv("MASTER_PORT", "29534")
     f.write_bytes(comm._header(2) + b"x" * 64)
     monkeypatch.setenv("MASTER_PORT", "29533")
     assert comm._read_fresh(f, 2, 64) is None                     # another job's port
     f.write_bytes(b"x" * 64)
     assert comm._read_fresh(f, 2, 64) is None                     # no header at all (what round 2 wrote)
+    old_header = b"DQLC" + (29533).to_bytes(4, "little") + (2).to_bytes(4, "little") + b"\0\0\0\0"
     # a full gather with leftovers of rank 1 in place: rank 0 must wait for the REAL rank 1
     base = comm.id_file_path(0)
     stale_bin = base.with_name(f"{base.stem}.t9.1.bin"); stale_done = base.with_name(f"{base.stem}.t9.1.done")
-    stale_bin.write_bytes(comm._header(2) + b"S" * 64); stale_done.write_bytes(comm._header(2))
-    os.utime(stale_bin, (old, old)); os.utime(stale_done, (old, old))
+    stale_bin.write_bytes(old_header + b"S" * 64 + b"\0" * 8); stale_done.write_bytes(old_header + b"\0" * 8)   # round 3's header: another "job"
     res = {}
 
     def run(rank, delay):

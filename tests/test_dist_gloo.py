@@ -275,3 +275,45 @@ def test_reducer_factory_without_sync_period_defaults_to_two(tmp_path, monkeypat
                    reducer_factory=LocalWindowReducer, checkpoint_every=10**9)
     eng, runner = tr._make_engine(tr._config(0))
     assert runner.sync_period == 2 and runner.reducer is not None
+
+
+def test_resume_with_a_mismatching_shard_stops_every_rank_after_the_vote(tmp_path, monkeypatch):
+    """an env-state shard holding another env count used to raise on ITS rank before the all-reduce of the resume vote, leaving the
+    other ranks in the collective.  Now the mismatch is part of the vote: every rank takes part in the collective and every rank raises."""
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+
+    class FakeComm:  # the other rank's votes are added to this rank's, as the all-reduce would
+        def __init__(self, other):
+            self.other, self.calls, self.rank, self.world = other, 0, 0, 2
+        def all_reduce_sum(self, v):
+            self.calls += 1
+            return np.asarray(v, dtype=np.float64) + np.asarray(self.other, dtype=np.float64)
+        def barrier(self):
+            pass
+
+    kw = dict(curriculum_steps=1, n_envs=32, chunk_steps=8, checkpoint_every=10**9, max_num_episodes=20, t_max=3, mode="paper")
+    tr = T.Trainer(save_path=tmp_path / "r" / "01-01-2026 10:00:00", **kw)
+    eng, _ = tr._make_engine(tr._config(0))
+    tr._engine = eng
+    tr._progress = {"level": 0, "steps": 8, "chunk_i": 1}
+    tr.save()
+    progress = dict(tr._progress, tag=tr._checkpoint_tag())
+    # (a) this rank's shard is fine, the OTHER rank reports a shard of another env count: this rank must not fly its shard either
+    tr._comm, tr._world = FakeComm([1.0, 1.0]), 2
+    progress["tag"]["world"] = 1  # the shard was written by a world of 1; keep the tags equal so that only the vote decides
+    with pytest.raises(ValueError, match="another rank"):
+        tr._restore_env_state(eng, progress)
+    assert tr._comm.calls == 1
+    # (b) the other rank merely has no shard (not an error): nobody flies, nobody raises
+    tr._comm = FakeComm([1.0, 0.0])
+    assert tr._restore_env_state(eng, progress) is False and tr._comm.calls == 1
+    # (c) this rank's own shard holds another env count: it still votes first, then raises with its own message
+    small, _ = T.Trainer(save_path=tmp_path / "s" / "01-01-2026 10:00:00", **dict(kw, n_envs=16))._make_engine(tr._config(0))
+    tr._comm = FakeComm([0.0, 0.0])
+    with pytest.raises(ValueError, match="holds 32 envs"):
+        tr._restore_env_state(small, progress)
+    assert tr._comm.calls == 1
+    # (d) all good on both ranks: the state is restored
+    tr._comm = FakeComm([0.0, 0.0])
+    assert tr._restore_env_state(eng, progress) is True
