@@ -111,15 +111,18 @@ def cpu_baseline(envs: int, steps: int, dtype: int, cfg_kw: dict):
             "single_thread_value": d1 / t1, "single_thread_sample": f"{envs} envs x {steps} agent periods ({d1} env-steps, {t1:.1f} s)"}
 
 
-# Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in the line).  quirks 0x60 = paper-mode MDP
-# (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only,
-# B1/B2): measured slightly ahead of Double Q-learning here (profiles/r2_curriculum_reference_counter_sweep8.jsonl,
-# r3_curriculum_32768_sweep1_variants.jsonl); 2 judged envs: the deque sees the episodes of 2 envs; 16 agent periods per launch and table
-# exchange every 16; eps_tail: level 0 follows the reference's exploration schedule, keeps its 0.01 floor for the first 192 episodes per
-# env and then stops exploring — tables that LEARN from the floor's exploratory transitions fly 41 % of level 0's episodes out of the fly
-# zone, the same tables learning on without them 0.6 % (profiles/r3_level0_eps_tail.jsonl); stopping right away starves the later
-# levels of visited states (profiles/r3_curriculum_sweep2_eps_tail_immediate.jsonl)
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 2, "periods_per_launch": 16, "eps_tail": 0.0, "eps_tail_after": 192}
+# Trainer keywords of the curriculum leg beyond the defaults (kept in one place: reported in bench_detail.json).  quirks 0x60 = paper-mode MDP
+# (reward / observation quirks repaired, the reference's success counter kept) + the reference's own update rule (Q_table_a only, B1/B2);
+# 16 agent periods per launch and table exchange every 16; eps_tail: level 0 follows the reference's exploration schedule, keeps its 0.01
+# floor for the first 192 episodes per env and then stops exploring (profiles/r3_level0_eps_tail.jsonl).
+# Promotion (round 4, profiles/r4_curriculum_gate_sweep.jsonl, 12 seeds per row): the reference's deque (100 episodes, > 0.96) is fed by the
+# episodes of 64 judged envs in generation order and is NECESSARY but no longer sufficient — the success rate of ALL envs over the most recent
+# chunks must reach population_gate = 0.94 as well (uniform starts cap the population near 0.95: a platform receding at 1.6 m/s from 4.5 m away
+# cannot be caught; a gate of 0.95 promotes all five levels in 1 seed of 12).  Round 3's rule (2 judged envs, no gate) promoted at population
+# rates down to 0.90; with the gate no promotion happens below 0.94, all five levels promote in 8 seeds of 12 (round 3: 6), the stage-4 tables
+# reach goal-hold 0.943 / touchdown 0.878 on average and 0.929 / 0.829 in the worst seed (round 3: 0.940 / 0.872, worst 0.889 / 0.781).
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 64, "periods_per_launch": 16, "eps_tail": 0.0, "eps_tail_after": 192, "population_gate": 0.94}
+CURRICULUM_BUDGET_PER_ENV = 768  # episodes per env and level before the next level starts anyway (the reference: 50 000 episodes of ONE env)
 CURRICULUM_SYNC = 16
 # tabular RL is seed-noisy (per seed: goal-hold 0.87-0.96, touchdown 0.70-0.95, profiles/r3_curriculum_p8_p16_judge_sweep.jsonl): twelve
 # full curricula, each reported; 2 / 4 judged envs and 8 / 16 periods per launch are all within that noise of each other
@@ -147,7 +150,7 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
         n_global = args.curriculum_envs * world
         # the reference's 50 000-episode budget per level assumes ONE env; with N envs at once it has to cover a few
         # generations of all of them, or a level ends before most envs have finished an episode (Trainer default)
-        budget = max(args.curriculum_budget, 384 * n_global)
+        budget = max(args.curriculum_budget, CURRICULUM_BUDGET_PER_ENV * n_global)
         runs = []
         for seed in CURRICULUM_SEEDS[:args.curriculum_seeds]:
             with tempfile.TemporaryDirectory() as d:
@@ -176,7 +179,7 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
                 "level0_promoted_per_seed": [bool(r["levels"][0]["promoted"]) for r in runs],
                 "population_success_at_promotion": {"min": min(pops) if pops else None, "mean": sum(pops) / len(pops) if pops else None,
                                                     "note": "success rate of ALL envs' episodes over the chunks holding the most recent >= 100 episodes when the judged envs' deque passed 0.96 / 100"},
-                "rule": "deque(100) of the judged envs' episodes in generation order, > 0.96, or the level's episode budget exhausted (pkg/trainer.py:187,218-232)",
+                "rule": "deque(100) of the 64 judged envs' episodes in generation order > 0.96 (pkg/trainer.py:218-232) AND population success >= 0.94, or the level's episode budget exhausted (:187)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "trained_worst_seed": {k: min(r["stage4_greedy_4096_episodes"][k] for r in runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},
@@ -401,7 +404,7 @@ def main():
     ap.add_argument("--curriculum-envs", type=int, default=32768, help="envs per GPU of the curriculum leg (BASELINE configs[3]: 262 144 / 8)")
     ap.add_argument("--curriculum-seeds", type=int, default=None,
                     help="how many of the twelve seeds to run; default 12 on one GPU, 2 with several (the scaling sweep re-runs the leg at every N: its throughput leg is the same at N = 1 either way)")
-    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 384 per env")
+    ap.add_argument("--curriculum-budget", type=int, default=50000, help="episodes per level before the next level starts (reference: 50000); at least 768 per env")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")

@@ -214,6 +214,9 @@ def training_config(level: int = 0, **kw) -> DqlConfig:
     return DqlConfig(working_curriculum_step=level, **kw)
 
 
+AS_LAUNCHED = dict(mp_t_x=1.0, noise_pos_sd=0.25, noise_vel_sd=0.1)  # as_launched_config's fields, for Trainer(env_kw=AS_LAUNCHED)
+
+
 def as_launched_config(level: int = 0, **kw) -> DqlConfig:
     """The parameters the reference's manager node actually RAN with under `roslaunch` — not the ones its launch file spells out.
 
@@ -224,7 +227,7 @@ def as_launched_config(level: int = 0, **kw) -> DqlConfig:
     The PID nodes read `~`-private names and are not affected (`pkg/pid.py:33-48`).  The reference's own Gazebo flight records
     decide between the two readings (tests/test_g14_gazebo.py, golden G14): 801 episodes at eps = 1 reach the goal state in 38.0 %; this
     simulator gives 37.0 % with these values and 27.3 % with the launch file's, far outside the 99 % interval."""
-    base = dict(working_curriculum_step=level, mp_t_x=1.0, noise_pos_sd=0.25, noise_vel_sd=0.1)
+    base = dict(working_curriculum_step=level, **AS_LAUNCHED)
     base.update(kw)
     return DqlConfig(**base)
 

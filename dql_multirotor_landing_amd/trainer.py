@@ -86,7 +86,8 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
-               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after")
+               "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after",
+               "population_gate", "env_kw")
 
 
 class Trainer:
@@ -99,7 +100,8 @@ class Trainer:
                  checkpoint_every: int = 50, max_steps_per_level: Optional[int] = None, quiet: bool = True,
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
-                 periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, comm=None, reducer_factory=None) -> None:
+                 periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, population_gate: Optional[float] = None,
+                 env_kw: Optional[Dict[str, Any]] = None, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -140,6 +142,14 @@ class Trainer:
         self._periods_per_launch = int(periods_per_launch)
         self._eps_tail = None if eps_tail is None else float(eps_tail)
         self._eps_tail_after = float(eps_tail_after)
+        # population_gate: with N envs at once the reference's deque sees the episodes of the judged env(s) only — a 97 / 100 window of one or two
+        # envs can pass while the population still fails 10 % of its episodes.  The gate keeps the reference's rule as it is and adds a second,
+        # necessary condition: the success rate of ALL envs over the chunks holding the most recent >= 100 episodes must reach the gate as well.
+        # None (default): the reference's rule alone.
+        self._population_gate = None if population_gate is None else float(population_gate)
+        # env_kw: DqlConfig fields of the simulated world beyond the Trainer's own arguments, e.g. config.AS_LAUNCHED (the parameters the
+        # reference's manager node resolved under roslaunch: platform 1 m/s, observation noise 0.25 m / 0.1 m/s — tests/test_g14_gazebo.py)
+        self._env_kw = dict(env_kw or {})
         if not 1 <= self._periods_per_launch <= 16 or self._chunk_steps % self._periods_per_launch:
             raise ValueError("periods_per_launch must be in 1..16 and divide chunk_steps")
         # device None: GPU LOCAL_RANK of a multi-rank launch (one process per GPU), GPU 0 of a single process; an explicit device wins
@@ -289,7 +299,7 @@ class Trainer:
     def _config(self, level: int) -> DqlConfig:
         return DqlConfig(working_curriculum_step=level, dtype=self._dtype, quirks=self._quirks,
                          t_max=self._t_max, z_init=self._z_init, f_ag=self._f_ag, p_max=self._p_max, init_sigma=self._p_max / 3,
-                         gamma=self._gamma, alpha_min=self._alpha_min, alpha_omega=self._omega, fold_per_step=self._fold_per_step)
+                         gamma=self._gamma, alpha_min=self._alpha_min, alpha_omega=self._omega, fold_per_step=self._fold_per_step, **self._env_kw)
 
     def _push_tables(self):
         a = self._double_q_learning_agent
@@ -489,6 +499,8 @@ class Trainer:
                         "Termination condition": {c: int(v) for c, v in zip(_TERMINAL, cc[4:])}}
                 chunk_i += 1
                 done_level = (hit is not None) if ordered else (rate > self._success_rate)
+                if done_level and self._population_gate is not None and rate < self._population_gate:
+                    done_level = False  # the judged envs' window passed, the population has not arrived: the level goes on (the deque keeps sliding)
                 if chunk_i % self._checkpoint_every == 0 and not done_level:
                     self._progress = {"level": k, "episodes": episodes, "steps": steps, "chunk_i": chunk_i, "window": [list(w) for w in window],
                                       "pw": pw.get_state(), "order": order.get_state()}

@@ -33,6 +33,11 @@ a = ap.parse_args()
 for spec in a.set:
     name, _, kvs = spec.partition(":")
     kw = {k: parse_val(v) for k, v in (kv.split("=") for kv in kvs.split(",") if kv)}
+    if kw.pop("as_launched", 0):  # the world the reference's manager node resolved under roslaunch (config.AS_LAUNCHED, golden G14)
+        from dql_multirotor_landing_amd.config import AS_LAUNCHED
+        kw["env_kw"] = dict(AS_LAUNCHED)
+    if "ppl" in kw:
+        kw["periods_per_launch"] = kw.pop("ppl")
     budget_per_env = kw.pop("budget_per_env", a.budget_per_env)
     envs = kw.pop("envs", a.envs)
     for seed in a.seeds:
@@ -50,10 +55,11 @@ for spec in a.set:
                 tot = {c: sum(float(x[f"Episode/Termination Condition/{c}"]) for x in tail) for c in
                        ("TERMINAL_SUCCESS", "TERMINAL_FLYZONE_X", "TERMINAL_TIMEOUT", "TERMINAL_MINIMUM_ALTITUDE", "TERMINAL_FLYZONE_Z", "TERMINAL_CONTACT")}
                 n_ep = max(1.0, sum(tot.values()))
-                levels.append({"level": h["level"], "promoted": h["promoted"], "episodes_per_env": round(h["episodes"] / envs, 1), "periods": h["agent_periods"],
+                levels.append({"level": h["level"], "promoted": h["promoted"], "pop": None if h["success_rate"] is None else round(h["success_rate"], 3), "episodes_per_env": round(h["episodes"] / envs, 1), "periods": h["agent_periods"],
                                "tail": {k.replace("TERMINAL_", "").lower(): round(v / n_ep, 3) for k, v in tot.items() if v}})
-            ev_t = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="training", quirks=Q_PAPER)
-            ev_s = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="simulation", quirks=Q_PAPER)
+            wk = kw.get("env_kw") or {}  # evaluated in the world it was trained in
+            ev_t = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="training", quirks=Q_PAPER, **wk)
+            ev_s = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="simulation", quirks=Q_PAPER, **wk)
             tr._engine.close()
         print(json.dumps({"set": name, "kw": kw, "envs": envs, "budget_per_env": budget_per_env, "seed": seed, "wall_s": round(wall, 2),
                           "wall_to_stage4_s": round(hist[3]["wall_since_start_s"], 2) if len(hist) > 3 else None,
