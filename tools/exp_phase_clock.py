@@ -7,6 +7,7 @@
 import json, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import lib_source_sha16
 import numpy as np
 from dql_multirotor_landing_amd.config import DqlConfig, F32
 from dql_multirotor_landing_amd.engine import Engine
@@ -29,5 +30,5 @@ for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
     per = tot / P
     print(json.dumps({"envs": n, "flavour": "cfg4" if flav else "shared platform", "periods_per_launch": P, "launch_us": ms * 1e3 / reps,
                       "cycles_per_wave_per_period": {NAMES[k]: round(per[k], 1) for k in range(7)}, "share": {NAMES[k]: round(tot[k] / tot.sum(), 4) for k in range(7)},
-                      "cycles_per_wave_per_launch": round(tot.sum(), 0), "implied_clock_ghz": round(tot.sum() / (ms * 1e6 / reps), 3)}), flush=True)
+                      "cycles_per_wave_per_launch": round(tot.sum(), 0), "implied_clock_ghz": round(tot.sum() / (ms * 1e6 / reps), 3), "source_sha16": lib_source_sha16()}), flush=True)
     e.close()
