@@ -5,7 +5,7 @@ curriculum training of the tabular Double-Q landing agent on one MI355X.
     python scripts/training.py [--envs 4096] [--mode reference|paper] [--out DIR] [--max-steps-per-level N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         scripts/training.py --envs 262144 --recipe bench         # BASELINE configs[3]: one rank per GPU, RCCL table exchange every 16 periods
-    python scripts/training.py --envs 32768 --recipe bench       # its per-GPU share on one GPU: the curriculum leg of bench.py (stage 4 after ~1.6 s)
+    python scripts/training.py --envs 32768 --recipe bench       # its per-GPU share on one GPU: the curriculum leg of bench.py (stage 4 after ~1.0 s)
 (torch.distributed.run is only the process launcher here; any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
 MASTER_PORT will do.  The ranks themselves never import PyTorch.)
 """
@@ -38,7 +38,7 @@ if __name__ == "__main__":
     ap.add_argument("--quirks", type=lambda v: int(v, 0), default=None, help="override of the mode's quirk set (include/dql.h DQL_Q_*), e.g. 0x60")
     ap.add_argument("--eps-tail", type=float, default=None, help="exploration rate of level 0 once the reference's schedule has decayed (default: the reference's 0.01 floor)")
     ap.add_argument("--eps-tail-after", type=float, default=0.0, help="... from this many episodes per env on")
-    ap.add_argument("--recipe", default=None, choices=["bench"], help="bench: the trainer settings of bench.py's curriculum leg (bench.CURRICULUM_KW, mode paper, sync 16, 384 episodes per env and level)")
+    ap.add_argument("--recipe", default=None, choices=["bench"], help="bench: the trainer settings of bench.py's curriculum leg (bench.CURRICULUM_KW incl. the population gate, mode paper, sync 16, 768 episodes per env and level)")
     ap.add_argument("--window", type=int, default=100, help="successive_successful_episodes (reference: 100)")
     a = ap.parse_args()
     import os
@@ -53,7 +53,7 @@ if __name__ == "__main__":
         import bench
         extra = dict(bench.CURRICULUM_KW)
         a.mode, a.sync_period, a.judge_envs = "paper", bench.CURRICULUM_SYNC, extra.pop("judge_envs")
-        a.max_episodes = a.max_episodes or 384 * a.envs
+        a.max_episodes = a.max_episodes or bench.CURRICULUM_BUDGET_PER_ENV * a.envs
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local if world > 1 else None,
                  promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
                  successive_successful_episodes=a.window,
