@@ -761,16 +761,25 @@ template <typename T> DQL_DEV void platform_eval(const SimK<T>& s, Env<T>& e) {
 // manager tick instead of a 45-instruction sincos.  The phase itself advances exactly as before and stays the persistent state: every period
 // starts again from sincos(phase), so the recurrence never runs for more than five steps (a few ulp).  sin / cos of delta: Taylor to delta^5 /
 // delta^6 for delta <= 0.25 rad (1e-8 relative; the reference platform steps 0.008 rad), det_sincos beyond (per lane).
+#ifdef DQL_PLATREC_LEAN  // A/B build: sin / cos of the step recomputed at every manager tick (9 instructions) instead of held in two registers across the tick loop
+template <typename T> struct PlatRec { T sn, cs; };
+#else
 template <typename T> struct PlatRec { T sn, cs, sd, cd; };
-template <typename T> DQL_DEV void platform_rec_begin(const SimK<T>& s, const Env<T>& e, PlatRec<T>& r) {
-  det_sincos(e.mp_phase, r.sn, r.cs);
+#endif
+template <typename T> DQL_DEV void platform_step_sincos(const SimK<T>& s, const Env<T>& e, T& sd, T& cd) {
   const T d = e.mp_w * s.mp_dt;
-  if (d > T(0.25) || d < T(-0.25)) det_sincos(d, r.sd, r.cd);
+  if (d > T(0.25) || d < T(-0.25)) det_sincos(d, sd, cd);
   else {
     const T z = d * d;
-    r.sd = d * fma_(z, fma_(z, T(8.33333333333333322e-03), T(-1.66666666666666657e-01)), T(1.0));
-    r.cd = fma_(z, fma_(z, fma_(z, T(-1.38888888888888894e-03), T(4.16666666666666644e-02)), T(-0.5)), T(1.0));
+    sd = d * fma_(z, fma_(z, T(8.33333333333333322e-03), T(-1.66666666666666657e-01)), T(1.0));
+    cd = fma_(z, fma_(z, fma_(z, T(-1.38888888888888894e-03), T(4.16666666666666644e-02)), T(-0.5)), T(1.0));
   }
+}
+template <typename T> DQL_DEV void platform_rec_begin(const SimK<T>& s, const Env<T>& e, PlatRec<T>& r) {
+  det_sincos(e.mp_phase, r.sn, r.cs);
+#ifndef DQL_PLATREC_LEAN
+  platform_step_sincos(s, e, r.sd, r.cd);
+#endif
 }
 // rec: the fused float32 step's per-period sine / cosine carry (null: evaluate sincos(phase) at this tick — float64, and the stand-alone operators)
 template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e, PlatRec<T>* rec = nullptr, bool first_in_period = true) {
@@ -778,8 +787,14 @@ template <typename T> DQL_DEV void platform_update(const SimK<T>& s, Env<T>& e, 
     if (first_in_period) platform_rec_begin(s, e, *rec);
     platform_set(s, e, rec->sn, rec->cs);
     const T sn = rec->sn, cs = rec->cs;
-    rec->sn = fma_(sn, rec->cd, cs * rec->sd);
-    rec->cs = fma_(cs, rec->cd, -(sn * rec->sd));
+#ifdef DQL_PLATREC_LEAN
+    T sd, cd;
+    platform_step_sincos(s, e, sd, cd);
+#else
+    const T sd = rec->sd, cd = rec->cd;
+#endif
+    rec->sn = fma_(sn, cd, cs * sd);
+    rec->cs = fma_(cs, cd, -(sn * sd));
   } else platform_eval(s, e);
   T ph = fma_(e.mp_w, s.mp_dt, e.mp_phase);
   if (ph >= T(6.28318530717958623200e+00)) ph -= T(6.28318530717958623200e+00);
@@ -1274,7 +1289,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   T R[9], cy, sy, ct = T(1.0), rn = T(1.0);
   uint32_t mgr_in_step = 0;
   PlatRec<T> prec;                      // platform sine / cosine carried between the manager ticks of this period (float32: platform_update)
-  prec.sn = prec.cs = prec.sd = prec.cd = T(0.0);
+  prec = PlatRec<T>{};
   int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
   long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
   // the period's last manager tick (wave-uniform): the only one whose observation noise is ever read (manager_obs)

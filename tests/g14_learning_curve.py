@@ -4,7 +4,7 @@
 Not a pytest module (a minute per seed): an experiment whose output is committed under profiles/ (r4_g14_learning_curves.jsonl).  Lives under
 tests/ because it drives the CPU oracle.
 
-    python tests/g14_learning_curve.py SEED [launched|file] [EPISODES]
+    python tests/g14_learning_curve.py SEED [launched|file] [EPISODES] [LEVEL-1 EPISODES after the promotion, e.g. 1256 as in the Gazebo run]
 
 The reference trains ONE env sequentially (`pkg/trainer.py:187-236`): `guess` (eps schedule of :112-126, `np.random` uniform + randint always
 drawn, B4) -> `env.step` -> `update` with alpha(pre-increment count) (B5), all quirks of SURVEY.md appendix B (quirks 0x7f: B1-B3 update
@@ -32,7 +32,10 @@ def eps_of(ep):  # pkg/trainer.py:112-126 at level 0
     return 1.0 if ep <= 800 else max(1 + (0.01 - 1) * (ep - 800) / 1200.0, 0.01)
 
 
-def run(seed, cfg, episodes):
+def run(seed, cfg, episodes, level1_episodes=0):
+    """-> (codes, steps) of level 0, and — when level1_episodes > 0 and the deque rule fired — of the level-1 episodes flown afterwards as the reference
+    flies them: `transfer_learning(0, 1.0)` first (B6: Q[0] = Q[-1] = zeros), then a new env at level 1 (uniform starts, eps = 0)"""
+    from oracle.oracle import transfer
     o = Oracle(cfg, 1, seed=seed)
     rng = np.random.RandomState(seed)
     rn, ino = o.field_names(False), o.field_names(True)
@@ -43,10 +46,14 @@ def run(seed, cfg, episodes):
     o.step(act)  # the env is created flagged for reset: this period places it and returns the first state (TrainingLandingEnv.reset)
     s = int(o.get_fields()[1][i_idx][0])
     codes, steps, ep = [], [], 0
+    codes1, steps1 = [], []
     sa, nsa, al, rw = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1), np.zeros(1)
-    while ep < episodes:
+    window = []
+    level = 0
+    while True:
+        eps = eps_of(ep) if level == 0 else 0.0
         u, ra = rng.uniform(), rng.randint(3)
-        a = ra if u < eps_of(ep) else int(np.argmax((qa[3 * s:3 * s + 3] + qb[3 * s:3 * s + 3]) / 2))
+        a = ra if u < eps else int(np.argmax((qa[3 * s:3 * s + 3] + qb[3 * s:3 * s + 3]) / 2))
         act[0] = a
         o.step(act)
         r, i = o.get_fields()
@@ -54,12 +61,23 @@ def run(seed, cfg, episodes):
         sa[0], nsa[0], al[0], rw[0] = 3 * s + a, i[i_idx][0], (atab[c] if c < len(atab) else cfg.alpha_min), r[i_rew][0]
         agent_update(qa, qb, cnt, sa, nsa, al, cfg.gamma, rw, quirks=cfg.quirks)
         if i[i_fl][0] & 1:
-            codes.append(int(i[i_code][0])); steps.append(int(i[i_sc][0])); ep += 1
+            code = int(i[i_code][0])
+            (codes if level == 0 else codes1).append(code); (steps if level == 0 else steps1).append(int(i[i_sc][0])); ep += 1
+            if level == 0:
+                window = (window + [int(code == GOAL)])[-100:]
+                if level1_episodes > 0 and sum(window) > 96:  # pkg/trainer.py:232-243: promotion, transfer of the FINISHED level (B6), next level's env
+                    transfer(qa, qb, 0, 1.0)
+                    o.set_curriculum(1)
+                    level, ep = 1, 0
+                elif ep >= episodes:
+                    break
+            elif ep >= level1_episodes:
+                break
             o.step(act)
             s = int(o.get_fields()[1][i_idx][0])
         else:
             s = int(nsa[0])
-    return np.array(codes), np.array(steps)
+    return np.array(codes), np.array(steps), np.array(codes1), np.array(steps1)
 
 
 def curve(codes, steps):
@@ -76,13 +94,21 @@ if __name__ == "__main__":
         d = np.load(ROOT / "tests" / "golden" / "g14_gazebo_episodes.npz")
         m = d["run"] == 1
         n0 = 18282  # level 0 of the run (tests/test_g14_gazebo.py)
-        print(json.dumps({"what": "reference + Gazebo, run 22-02-2025 21:37:06, level 0 (golden G14)", **curve(d["code"][m][:n0], d["steps"][m][:n0])}))
+        c1, s1 = d["code"][m][n0:], d["steps"][m][n0:]
+        print(json.dumps({"what": "reference + Gazebo, run 22-02-2025 21:37:06, level 0 (golden G14)", **curve(d["code"][m][:n0], d["steps"][m][:n0]),
+                          "level1": {"episodes": int(len(c1)), "mix": {CHECK_NAMES[k]: round(float((c1 == k).mean()), 4) for k in np.unique(c1)},
+                                     "steps_mean": round(float(s1.mean()), 1), "steps_median": float(np.median(s1))}}))
         sys.exit(0)
     seed = int(sys.argv[1])
     which = sys.argv[2] if len(sys.argv) > 2 else "launched"
     episodes = int(sys.argv[3]) if len(sys.argv) > 3 else 19000
     cfg = as_launched_config(dtype=F64) if which == "launched" else DqlConfig(dtype=F64)
     t0 = time.time()
-    codes, steps = run(seed, cfg, episodes)
-    print(json.dumps({"what": f"this simulator (oracle, float64, N = 1, sequential reference algorithm, quirks 0x7f), parameters: {which}", "seed": seed,
-                      **curve(codes, steps), "wall_s": round(time.time() - t0, 1)}), flush=True)
+    l1 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    codes, steps, codes1, steps1 = run(seed, cfg, episodes, l1)
+    out = {"what": f"this simulator (oracle, float64, N = 1, sequential reference algorithm, quirks 0x7f), parameters: {which}", "seed": seed, **curve(codes, steps)}
+    if l1 and len(codes1):
+        out["level1"] = {"episodes": int(len(codes1)), "mix": {CHECK_NAMES[k]: round(float((codes1 == k).mean()), 4) for k in np.unique(codes1)},
+                         "steps_mean": round(float(steps1.mean()), 1), "steps_median": float(np.median(steps1))}
+    out["wall_s"] = round(time.time() - t0, 1)
+    print(json.dumps(out), flush=True)
