@@ -19,10 +19,12 @@ if __name__ == "__main__":
     from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
     from dql_multirotor_landing_amd.landing_simulation_env import TrainingLandingEnv
     from dql_multirotor_landing_amd.trainer import Trainer
-    with tempfile.TemporaryDirectory() as d:
+    from dql_multirotor_landing_amd.config import F32, F64
+
+    def loop(dtype, d):
         tr = Trainer(save_path=Path(d) / "run", n_envs=1)  # np.random.seed(42) as the reference's Trainer does
         agent = tr._double_q_learning_agent
-        env = TrainingLandingEnv(0, t_max=20, f_ag=22.92, p_max=4.5, z_init=4.0)
+        env = TrainingLandingEnv(0, t_max=20, f_ag=22.92, p_max=4.5, z_init=4.0, dtype=dtype)
         steps, episodes = 0, 0
         t0 = time.perf_counter()
         while steps < 1000:
@@ -35,10 +37,19 @@ if __name__ == "__main__":
                 s = s2; steps += 1
             episodes += 1
         wall = time.perf_counter() - t0
+        env.close()
+        return agent, steps, episodes, wall
+
+    with tempfile.TemporaryDirectory() as d:
+        agent, steps, episodes, wall = loop(F64, d)
         agent.save(Path(d))
         back = DoubleQLearningAgent.load(Path(d))
         ok = np.array_equal(back.Q_table_a, agent.Q_table_a) and np.array_equal(back.state_action_counter, agent.state_action_counter)
+    with tempfile.TemporaryDirectory() as d:  # the same loop with the float32 step (TrainingLandingEnv(dtype=F32), build-specific keyword)
+        _, steps32, _, wall32 = loop(F32, d)
     print(json.dumps({"config": "BASELINE configs[0]: 1 env, x-axis, level 0, 1000 steps, single-env drop-in API on the GPU",
                       "steps": steps, "episodes": episodes, "wall_s": wall, "env_steps_per_s": steps / wall,
                       "visits": float(agent.state_action_counter.sum()), "npy_round_trip_ok": bool(ok),
-                      "reference_gazebo_env_steps_per_s": 20.18}))
+                      "float32_env_steps_per_s": steps32 / wall32,
+                      "note": "env_steps_per_s: float64 env (the default: the reference's expressions, what golden G13 pins); float32_env_steps_per_s: TrainingLandingEnv(dtype=F32)",
+                      "reference_gazebo_env_steps_per_s": 20.18, "reference_python_mdp_plus_agent_env_steps_per_s": 14400}))

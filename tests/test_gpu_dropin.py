@@ -370,3 +370,29 @@ def test_agent_tables_are_live_host_arrays():
             with pytest.raises(ValueError):
                 a.predict((0, 0, 0, 0, 0))
             a.close()
+
+
+def test_training_env_float32_keyword():
+    """`TrainingLandingEnv(dtype=F32)` (build-specific keyword): the same API on the float32 step.  Same seed, same scripted actions: the first
+    periods of an episode give the same discrete states as the float64 env except where an observation sits within rounding of a bin edge."""
+    from dql_multirotor_landing_amd.config import F32
+    from dql_multirotor_landing_amd.landing_simulation_env import TrainingLandingEnv
+    e64 = TrainingLandingEnv(0, z_init=4.0, seed=11)
+    e32 = TrainingLandingEnv(0, z_init=4.0, seed=11, dtype=F32)
+    rng = np.random.default_rng(3)
+    same = total = 0
+    for _ in range(6):
+        s64, s32 = e64.reset(), e32.reset()
+        assert len(s32) == 5 and all(isinstance(x, int) for x in s32)
+        same += s64 == s32; total += 1
+        for _ in range(25):
+            a = int(rng.integers(0, 3))
+            o64, o32 = e64.step(a), e32.step(a)
+            assert np.isfinite(o32[1]) and isinstance(o32[2], bool) and isinstance(o32[3], dict)
+            same += o64[0] == o32[0]; total += 1
+            if o64[2] or o32[2]:
+                break
+    assert same / total > 0.9, (same, total)
+    with pytest.raises(ValueError):
+        e32.step(0, 1)
+    e64.close(); e32.close()
