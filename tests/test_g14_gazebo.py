@@ -198,3 +198,24 @@ def test_g14_random_policy_statistics_hip(dtype):
     res = compare_with_gazebo(code, steps, cum)
     print(_report(res))
     assert all(v[2] for v in res.values()), "\n" + _report(res)
+
+
+def test_g14_sequential_reference_learner_first_two_thousand_episodes():
+    """G14, second cut, in short: the reference's OWN one-env algorithm (`guess` -> `env.step` -> `update` with alpha(pre-increment count), its eps
+    schedule, all quirks) on the oracle's one-env step with external actions + the oracle's sequential `agent_update` — the path the single-env
+    drop-in classes take — for the first 2 000 episodes of level 0, one seed, ~10 s.  The eps = 1 block (episodes 0 .. 800) must again sit inside
+    the Gazebo sample's 99 % interval (a different code path from the batched random-policy test above), and the eps-decay block (episodes
+    1 000 .. 2 000) near the Gazebo run's 0.538: 0.55 .. 0.60 over 8 seeds (profiles/r4_g14_learning_curves.jsonl, 19 000 episodes per seed and on
+    through the B6 collapse at level 1); a loose band here, the learner is seed-noisy."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import g14_learning_curve as lc
+    codes, steps, _, _ = lc.run(3, as_launched_config(dtype=F64), 2000)
+    gc, gs, _ = gazebo_random_policy_block()
+    lo, hi = wilson((gc == GOAL).sum(), len(gc))
+    p0 = (codes[:801] == GOAL).mean()
+    assert lo <= p0 <= hi, (p0, lo, hi)
+    g = gazebo_run()
+    gaz = (g["code"][1000:2000] == GOAL).mean()
+    p1 = (codes[1000:2000] == GOAL).mean()
+    assert 0.5 < gaz < 0.58 and abs(p1 - gaz) < 0.12, (p1, gaz)
+    assert abs(steps[:801].mean() - gs.mean()) < 8.0
