@@ -601,7 +601,7 @@ def committed_clock(envs: int, cfg4: bool):
                 rows.append(json.loads(ln))
             except ValueError:
                 pass
-        rows = [r for r in rows if r.get("envs") == envs and 0.5 < r.get("implied_clock_ghz", 0) <= 2.6]  # (an oversubscribed batch's waves do not all run at once: no clock)
+        rows = [r for r in rows if r.get("envs") == envs and 1.2 < r.get("implied_clock_ghz", 0) <= 2.6]  # (an oversubscribed batch's waves do not all run at once: cycles / time is no clock there — 0.5 "GHz" at 1 M envs)
         rows.sort(key=lambda r: (r.get("flavour") == "cfg4") == cfg4, reverse=True)
         if rows:
             return rows[0]["implied_clock_ghz"], f.name

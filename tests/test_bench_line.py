@@ -124,3 +124,14 @@ def test_default_seed_count_depends_on_gpus():
     assert "args.curriculum_seeds = 12 if args.gpus == 1 else 2" in src
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--curriculum-seeds" in r.stdout
+
+
+def test_measured_clock_ignores_oversubscribed_batches():
+    """at 1 M envs 16 waves share a SIMD and do not all run at once: the phase-clock file's cycles / time is 0.5 "GHz" there — not a clock, and a
+    fraction priced with it would exceed 1 (round 4's first campaign printed 3.4)"""
+    ghz, _ = bench.committed_clock(1048576, True)
+    assert ghz is None
+    ghz, src = bench.committed_clock(131072, True)
+    assert ghz is not None and 1.5 < ghz < 2.5 and src.startswith("r")
+    v = bench.valu_issue(1048576, 16, 0, 1, 1, "f32", 2.04, 16)
+    assert v is None or v.get("frac_at_measured_clock") is None or v["frac_at_measured_clock"] <= 1.0
