@@ -255,6 +255,7 @@ template <typename T> struct SimK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   T dtm, dtg, dtI[3];  // dt / m, dt g, dt / I: the float32 tick integrates with them (one fma per component, see FAST32)
   T oup, odn, inv_mgr_dt;  // 1 - rotor alpha (up / down), 1 / (dt manager_div): float32 tick
+  T nlcd, hdt, low_z;      // -(l c_d), dt / 2, mp_top + bottom: float32 tick (round 4b)
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -274,7 +275,7 @@ template <typename T> struct SimK {
 DQL_DEV float to_vgpr(float x) { float y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 template <typename T> struct HotK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, lkf, kmkf, aup, adn, omax, cd, crd;
-  T dtm, dtg, dtI[3], oup, odn;
+  T dtm, dtg, dtI[3], oup, odn, nlcd, hdt, low_z;
   T kR[3], kW[3], ia, ib, ic;
   T vz_kp, vz_ki, vz_lo, vz_hi, vz_wind, vz_sp;
   T yw_kp, yw_ki, yw_lo, yw_hi, yw_wind, yw_sp;
@@ -285,7 +286,7 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   HotK<float> h;
 #define DQL_HOT(f) h.f = to_vgpr(s.f)
   DQL_HOT(dt); DQL_HOT(g); DQL_HOT(inv_m); DQL_HOT(I[0]); DQL_HOT(I[1]); DQL_HOT(I[2]); DQL_HOT(inv_I[0]); DQL_HOT(inv_I[1]); DQL_HOT(inv_I[2]);
-  DQL_HOT(dtm); DQL_HOT(dtg); DQL_HOT(dtI[0]); DQL_HOT(dtI[1]); DQL_HOT(dtI[2]); DQL_HOT(oup); DQL_HOT(odn);
+  DQL_HOT(dtm); DQL_HOT(dtg); DQL_HOT(dtI[0]); DQL_HOT(dtI[1]); DQL_HOT(dtI[2]); DQL_HOT(oup); DQL_HOT(odn); DQL_HOT(nlcd); DQL_HOT(hdt); DQL_HOT(low_z);
   DQL_HOT(l); DQL_HOT(h); DQL_HOT(kf); DQL_HOT(lkf); DQL_HOT(kmkf); DQL_HOT(aup); DQL_HOT(adn); DQL_HOT(omax); DQL_HOT(cd); DQL_HOT(crd);
   DQL_HOT(kR[0]); DQL_HOT(kR[1]); DQL_HOT(kR[2]); DQL_HOT(kW[0]); DQL_HOT(kW[1]); DQL_HOT(kW[2]); DQL_HOT(ia); DQL_HOT(ib); DQL_HOT(ic);
   DQL_HOT(vz_kp); DQL_HOT(vz_ki); DQL_HOT(vz_lo); DQL_HOT(vz_hi); DQL_HOT(vz_wind); DQL_HOT(vz_sp);
@@ -697,19 +698,36 @@ template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e,
   const T l = s.l, h = s.h;
   const T w0 = e.w[0], w1 = e.w[1], w2 = e.w[2];
   // thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
-  const T q0 = e.om[0] * e.om[0], q1 = e.om[1] * e.om[1], q2 = e.om[2] * e.om[2], q3 = e.om[3] * e.om[3];
-  const T Fbz = s.kf * ((q0 + q1) + (q2 + q3));
-  T tx = s.lkf * (q1 - q3), ty = s.lkf * (q2 - q0), tz = s.kmkf * ((q0 - q1) + (q2 - q3));
+  T Fbz, tx, ty, tz, S, d02, d13;
+  if constexpr (Fast32<T>::on) {
+    // round 4b: opposite rotors first — the sums and differences of the speeds of arm x (0, 2) and arm y (1, 3) serve the thrust torques
+    // (q1 - q3 = (om1 - om3)(om1 + om3)), the drag sums and the total alike; squares by fma: 17 instructions instead of 21
+    const T s02 = e.om[0] + e.om[2], s13 = e.om[1] + e.om[3];
+    d02 = e.om[0] - e.om[2]; d13 = e.om[1] - e.om[3];
+    S = s02 + s13;
+    const T qa_ = fma_(e.om[0], e.om[0], e.om[2] * e.om[2]), qb_ = fma_(e.om[1], e.om[1], e.om[3] * e.om[3]);  // q0 + q2, q1 + q3
+    Fbz = s.kf * (qa_ + qb_);
+    tx = s.lkf * (d13 * s13); ty = -(s.lkf * (d02 * s02)); tz = s.kmkf * (qa_ - qb_);
+  } else {
+    const T q0 = e.om[0] * e.om[0], q1 = e.om[1] * e.om[1], q2 = e.om[2] * e.om[2], q3 = e.om[3] * e.om[3];
+    Fbz = s.kf * ((q0 + q1) + (q2 + q3));
+    tx = s.lkf * (q1 - q3); ty = s.lkf * (q2 - q0); tz = s.kmkf * ((q0 - q1) + (q2 - q3));
+    S = (e.om[0] + e.om[1]) + (e.om[2] + e.om[3]); d02 = e.om[0] - e.om[2]; d13 = e.om[1] - e.om[3];
+  }
   // rotor drag -|om_i| c_d v_perp,i with v_perp,i = (v_body + w x r_i) restricted to the rotor plane, summed in closed form:
   // sum_i om_i (w x r_i)_x = S w_y h - w_z l (om1 - om3),  sum_i om_i (w x r_i)_y = -S w_x h + w_z l (om0 - om2)
   const T vbx = fma_(R[0], e.v[0], fma_(R[3], e.v[1], R[6] * e.v[2]));
   const T vby = fma_(R[1], e.v[0], fma_(R[4], e.v[1], R[7] * e.v[2]));
   const T uxc = fma_(w1, h, vbx), uyc = fma_(-w0, h, vby), wzl = w2 * l;
-  const T S = (e.om[0] + e.om[1]) + (e.om[2] + e.om[3]), d02 = e.om[0] - e.om[2], d13 = e.om[1] - e.om[3];
   const T Fbx = -(s.cd * fma_(S, uxc, -(wzl * d13)));
   const T Fby = -(s.cd * fma_(S, uyc, wzl * d02));
-  const T tzd = -(s.cd * fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))));  // sum_i (r_i x drag_i)_z / l
-  tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, tzd, tz);
+  if constexpr (Fast32<T>::on) {  // the drag's yaw torque with -(l c_d) as one host constant
+    tz = fma_(T(s.nlcd), fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))), tz);
+    tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty);
+  } else {
+    const T tzd = -(s.cd * fma_(uyc, d02, fma_(wzl, S, -(uxc * d13))));  // sum_i (r_i x drag_i)_z / l
+    tx = fma_(-h, Fby, tx); ty = fma_(h, Fbx, ty); tz = fma_(l, tzd, tz);
+  }
   tx = fma_(s.crd, Fbx, tx); ty = fma_(s.crd, Fby, ty);  // rolling moment = (c_r / c_d) * drag force
   const T Fwx = fma_(R[0], Fbx, fma_(R[1], Fby, R[2] * Fbz)), Fwy = fma_(R[3], Fbx, fma_(R[4], Fby, R[5] * Fbz)), Fwz = fma_(R[6], Fbx, fma_(R[7], Fby, R[8] * Fbz));
   if constexpr (Fast32<T>::on) {
@@ -731,12 +749,22 @@ template <typename T, typename K> DQL_DEV void plant_step(const K& s, Env<T>& e,
     e.w[1] = fma_(s.dt, (ty - g1) * s.inv_I[1], w1);
     e.w[2] = fma_(s.dt, (tz - g2) * s.inv_I[2], w2);
   }
-  const T qw = e.q[0], qx = e.q[1], qy = e.q[2], qz = e.q[3], hdt = T(0.5) * s.dt;
-  const T dw = -fma_(qx, e.w[0], fma_(qy, e.w[1], qz * e.w[2]));
-  const T dxq = fma_(qw, e.w[0], fma_(qy, e.w[2], -(qz * e.w[1])));
-  const T dyq = fma_(qw, e.w[1], fma_(qz, e.w[0], -(qx * e.w[2])));
-  const T dzq = fma_(qw, e.w[2], fma_(qx, e.w[1], -(qy * e.w[0])));
-  const T nw = fma_(hdt, dw, qw), nx = fma_(hdt, dxq, qx), ny = fma_(hdt, dyq, qy), nz = fma_(hdt, dzq, qz);
+  const T qw = e.q[0], qx = e.q[1], qy = e.q[2], qz = e.q[3];
+  T nw, nx, ny, nz;
+  if constexpr (Fast32<T>::on) {  // round 4b: the body rates scaled by dt / 2 once, every component three fmas onto the old one: 15 instructions instead of 17
+    const T h0 = T(s.hdt) * e.w[0], h1 = T(s.hdt) * e.w[1], h2 = T(s.hdt) * e.w[2];
+    nw = fma_(-qx, h0, fma_(-qy, h1, fma_(-qz, h2, qw)));
+    nx = fma_(qw, h0, fma_(qy, h2, fma_(-qz, h1, qx)));
+    ny = fma_(qw, h1, fma_(qz, h0, fma_(-qx, h2, qy)));
+    nz = fma_(qw, h2, fma_(qx, h1, fma_(-qy, h0, qz)));
+  } else {
+    const T hdt = T(0.5) * s.dt;
+    const T dw = -fma_(qx, e.w[0], fma_(qy, e.w[1], qz * e.w[2]));
+    const T dxq = fma_(qw, e.w[0], fma_(qy, e.w[2], -(qz * e.w[1])));
+    const T dyq = fma_(qw, e.w[1], fma_(qz, e.w[0], -(qx * e.w[2])));
+    const T dzq = fma_(qw, e.w[2], fma_(qx, e.w[1], -(qy * e.w[0])));
+    nw = fma_(hdt, dw, qw); nx = fma_(hdt, dxq, qx); ny = fma_(hdt, dyq, qy); nz = fma_(hdt, dzq, qz);
+  }
   // renormalise with one Newton step of 1/sqrt(|q|^2) about 1: |q|^2 - 1 = O((dt |w|)^2), so the residual is O(dt^4)
   const T inv = fma_(T(-0.5), fma_(nw, nw, fma_(nx, nx, fma_(ny, ny, nz * nz))), T(1.5));
   e.q[0] = nw * inv; e.q[1] = nx * inv; e.q[2] = ny * inv; e.q[3] = nz * inv;
@@ -854,7 +882,9 @@ template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<
   e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
   // the footprint test only where some lane of the wave is low enough to touch (a real branch: a training flight descends at 0.1 m/s from
   // 4 m and ends after 20 s at the latest — it never gets there, and the tick pays two instructions instead of eight)
-  const bool low = e.p[2] - s.bottom <= s.mp_top;
+  bool low;
+  if constexpr (Fast32<T>::on) low = e.p[2] <= T(s.low_z);  // round 4b: against the host's mp_top + bottom
+  else low = e.p[2] - s.bottom <= s.mp_top;
   if (__ballot(low) != 0ull) {
     asm volatile("; footprint test" ::: "memory");  // keeps the block a block: the compiler otherwise flattens it into selects again
     if (low && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
@@ -905,7 +935,7 @@ DQL_DEV float opq(float x) { asm("" : "+v"(x)); return x; }
 DQL_DEV double opq(double x) { return x; }
 DQL_DEV f2 mk2(float a, float b) { return f2{opq(a), opq(b)}; }
 struct TickPk {
-  f2 q_wx, q_yz, w01, v01, p01, om02, om13;
+  f2 q_wx, q_yz, w01, v01, p01, omA, omB;  // rotors: A = (0, 1), B = (2, 3): opposite rotors sit in the same half of their pairs
   float w2, v2, p2;
   f2 pid_i, pid_x1, pid_x2, pid_y1, pid_state;  // (v_z controller, yaw controller); x1, x2, y1 = the transposed Butterworth's t1, t2, t3
   f2 mp_xy, mp_uv;
@@ -917,7 +947,7 @@ DQL_DEV void pack_tick(const Env<float>& e, TickPk& s) {
   s.w01 = mk2(e.w[0], e.w[1]); s.w2 = e.w[2];
   s.v01 = mk2(e.v[0], e.v[1]); s.v2 = e.v[2];
   s.p01 = mk2(e.p[0], e.p[1]); s.p2 = e.p[2];
-  s.om02 = mk2(e.om[0], e.om[2]); s.om13 = mk2(e.om[1], e.om[3]);
+  s.omA = mk2(e.om[0], e.om[1]); s.omB = mk2(e.om[2], e.om[3]);
   s.pid_i = mk2(e.vz_i, e.yw_i); s.pid_x1 = mk2(e.vz_x1, e.yw_x1); s.pid_x2 = mk2(e.vz_x2, e.yw_x2);
   s.pid_y1 = mk2(e.vz_y1, e.yw_y1);
   s.pid_state = mk2(e.vz_state, e.yw_state);
@@ -928,7 +958,7 @@ DQL_DEV void unpack_tick(const TickPk& s, Env<float>& e) {
   e.w[0] = opq(s.w01.x); e.w[1] = opq(s.w01.y); e.w[2] = s.w2;
   e.v[0] = opq(s.v01.x); e.v[1] = opq(s.v01.y); e.v[2] = s.v2;
   e.p[0] = opq(s.p01.x); e.p[1] = opq(s.p01.y); e.p[2] = s.p2;
-  e.om[0] = opq(s.om02.x); e.om[2] = opq(s.om02.y); e.om[1] = opq(s.om13.x); e.om[3] = opq(s.om13.y);
+  e.om[0] = opq(s.omA.x); e.om[1] = opq(s.omA.y); e.om[2] = opq(s.omB.x); e.om[3] = opq(s.omB.y);
   e.vz_i = opq(s.pid_i.x); e.yw_i = opq(s.pid_i.y); e.vz_x1 = opq(s.pid_x1.x); e.yw_x1 = opq(s.pid_x1.y); e.vz_x2 = opq(s.pid_x2.x); e.yw_x2 = opq(s.pid_x2.y);
   e.vz_y1 = opq(s.pid_y1.x); e.yw_y1 = opq(s.pid_y1.y);
   e.vz_state = opq(s.pid_state.x); e.yw_state = opq(s.pid_state.y);
@@ -1017,28 +1047,28 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   const f2 M01 = pfma(-eW01, k.kW01, swp2(hh) * k.kRn);                     // fma(-eW0, kW0, -(eR0 kR0)), fma(-eW1, kW1, -(eR1 kR1))
   const float M2 = fma_(-eW2, (float)c.kW[2], -(dR2 * (0.5f * (float)c.kR[2])));
   const float a = thrust * c.ia;
-  const f2 ibn = f2{-(float)c.ib, (float)c.ib};
-  const f2 w2_02 = pfma(bc2(M2), bc2((float)c.ic), pfma(hi2(M01), ibn, bc2(a)));          // fma(M2, ic, fma(-+M1, ib, a))
-  const f2 w2_13 = pfma(bc2(M2), bc2(-(float)c.ic), pfma(lo2(M01), swp2(ibn), bc2(a)));   // fma(-M2, ic, fma(+-M0, ib, a))
-  const f2 cmd02 = f2{rotor_cmd(c, w2_02.x), rotor_cmd(c, w2_02.y)};
-  const f2 cmd13 = f2{rotor_cmd(c, w2_13.x), rotor_cmd(c, w2_13.y)};
+  const f2 ibn = f2{-(float)c.ib, (float)c.ib}, icn = f2{(float)c.ic, -(float)c.ic};
+  const f2 w2_A = pfma(bc2(M2), icn, pfma(swp2(M01), ibn, bc2(a)));          // rotors 0, 1: fma(+-M2, ic, fma(-M1 | +M0, ib, a))
+  const f2 w2_B = pfma(bc2(M2), icn, pfma(swp2(M01), f2{(float)c.ib, -(float)c.ib}, bc2(a)));  // rotors 2, 3: fma(+-M2, ic, fma(+M1 | -M0, ib, a))
+  const f2 cmdA = f2{rotor_cmd(c, w2_A.x), rotor_cmd(c, w2_A.y)};
+  const f2 cmdB = f2{rotor_cmd(c, w2_B.x), rotor_cmd(c, w2_B.y)};
   // ---- rotor forces from the CURRENT rotor speeds + rigid body (gazebo_motor_model.cpp:434-500) ----
   const float l = c.l, h = c.h;
-  const f2 q02 = s.om02 * s.om02, q13 = s.om13 * s.om13;
-  const f2 qs = q02 + q13;                                                  // (q0 + q1, q2 + q3)
-  const float Fbz = c.kf * (qs.x + qs.y);
-  const f2 qd = q02 - q13;                                                  // (q0 - q1, q2 - q3)
-  float tz = c.kmkf * (qd.x + qd.y);
-  f2 txy = bc2(c.lkf) * f2{q13.x - q13.y, q02.y - q02.x};
+  // (plant_step, float32 form: sums and differences of opposite rotors' speeds first)
+  const f2 so = s.omA + s.omB, dd = s.omA - s.omB;                           // (s02, s13), (d02, d13)
+  const float S = so.x + so.y, d02 = dd.x, d13 = dd.y;
+  const f2 qab = pfma(s.omA, s.omA, s.omB * s.omB);                          // (q0 + q2, q1 + q3)
+  const float Fbz = c.kf * (qab.x + qab.y);
+  float tz = c.kmkf * (qab.x - qab.y);
+  const f2 ds = dd * so;                                                     // (d02 s02, d13 s13)
+  f2 txy = bc2(c.lkf) * f2{ds.y, -ds.x};                                     // lkf (d13 s13), -(lkf (d02 s02))
   const f2 vb = pfma(r.R01, lo2(s.v01), pfma(r.R34, hi2(s.v01), r.R67 * bc2(s.v2)));
   const f2 u = pfma(f2{s.w01.y, -s.w01.x}, bc2(h), vb);                     // (uxc, uyc)
   const float wzl = s.w2 * l;
-  const f2 os = s.om02 + s.om13;                                            // (om0 + om1, om2 + om3)
-  const float S = os.x + os.y, d02 = s.om02.x - s.om02.y, d13 = s.om13.x - s.om13.y;
-  const f2 md = bc2(wzl) * f2{d13, d02};
+  const f2 md = bc2(wzl) * swp2(dd);                                         // wzl (d13, d02)
   const f2 F = -(bc2(c.cd) * pfma(bc2(S), u, f2{-md.x, md.y}));             // (Fbx, Fby)
-  const float tzd = -(c.cd * fma_(u.y, d02, fma_(wzl, S, -(u.x * d13))));
-  txy = pfma(f2{-h, h}, swp2(F), txy); tz = fma_(l, tzd, tz);
+  tz = fma_((float)c.nlcd, fma_(u.y, d02, fma_(wzl, S, -(u.x * d13))), tz);
+  txy = pfma(f2{-h, h}, swp2(F), txy);
   txy = pfma(bc2(c.crd), F, txy);
   const float Fwx = fma_(r.R04.x, F.x, fma_(r.R13.x, F.y, r.R26.x * Fbz));
   const float Fwy = fma_(r.R13.y, F.x, fma_(r.R04.y, F.y, r.R57.x * Fbz));
@@ -1052,27 +1082,28 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   if ((float)c.I[0] == (float)c.I[1]) s.w2 = fma_((float)c.dtI[2], tz, w2);  // (w x I w)_z = 0 for I_x = I_y (plant_step)
   else s.w2 = fma_((float)c.dtI[2], tz - fma_(w0, Iw01.y, -(w1 * Iw01.x)), w2);
   {
-    const float qw = s.q_wx.x, qx = s.q_wx.y, qy = s.q_yz.x, qz = s.q_yz.y, hdt = 0.5f * c.dt;
-    const float nw0 = s.w01.x, nw1 = s.w01.y, nw2 = s.w2;
-    const float dw = -fma_(qx, nw0, fma_(qy, nw1, qz * nw2));
-    const float dxq = fma_(qw, nw0, fma_(qy, nw2, -(qz * nw1)));
-    const float dyq = fma_(qw, nw1, fma_(qz, nw0, -(qx * nw2)));
-    const float dzq = fma_(qw, nw2, fma_(qx, nw1, -(qy * nw0)));
-    const f2 n_wx = pfma(bc2(hdt), f2{dw, dxq}, s.q_wx), n_yz = pfma(bc2(hdt), f2{dyq, dzq}, s.q_yz);
-    const float inv = fma_(-0.5f, fma_(n_wx.x, n_wx.x, fma_(n_wx.y, n_wx.y, fma_(n_yz.x, n_yz.x, n_yz.y * n_yz.y))), 1.5f);
-    s.q_wx = n_wx * bc2(inv); s.q_yz = n_yz * bc2(inv);
+    const float qw = s.q_wx.x, qx = s.q_wx.y, qy = s.q_yz.x, qz = s.q_yz.y;
+    const f2 h01 = bc2((float)c.hdt) * s.w01; const float h2 = (float)c.hdt * s.w2;  // (plant_step, float32 form)
+    const float h0 = h01.x, h1 = h01.y;
+    // scalar fmas: the operands change partner at every level (a pair per level would have to be assembled by moves)
+    const float nw = fma_(-qx, h0, fma_(-qy, h1, fma_(-qz, h2, qw)));
+    const float nx = fma_(qw, h0, fma_(qy, h2, fma_(-qz, h1, qx)));
+    const float ny = fma_(qw, h1, fma_(qz, h0, fma_(-qx, h2, qy)));
+    const float nz = fma_(qw, h2, fma_(qx, h1, fma_(-qy, h0, qz)));
+    const float inv = fma_(-0.5f, fma_(nw, nw, fma_(nx, nx, fma_(ny, ny, nz * nz))), 1.5f);
+    s.q_wx = f2{nw * inv, nx * inv}; s.q_yz = f2{ny * inv, nz * inv};
   }
   // ---- first-order rotor speed filter (common.h:147-183), speed limit (gazebo_motor_model.cpp:358-364) ----
   {
-    const f2 d02 = cmd02 - s.om02, d13 = cmd13 - s.om13;  // rotor_cmd() clamped at omax already
-    const f2 c02 = f2{d02.x > 0.0f ? (float)c.oup : (float)c.odn, d02.y > 0.0f ? (float)c.oup : (float)c.odn};
-    const f2 c13 = f2{d13.x > 0.0f ? (float)c.oup : (float)c.odn, d13.y > 0.0f ? (float)c.oup : (float)c.odn};
-    s.om02 = pfma(c02, d02, s.om02);
-    s.om13 = pfma(c13, d13, s.om13);
+    const f2 dA = cmdA - s.omA, dB = cmdB - s.omB;  // rotor_cmd() clamped at omax already
+    const f2 cA = f2{dA.x > 0.0f ? (float)c.oup : (float)c.odn, dA.y > 0.0f ? (float)c.oup : (float)c.odn};
+    const f2 cB = f2{dB.x > 0.0f ? (float)c.oup : (float)c.odn, dB.y > 0.0f ? (float)c.oup : (float)c.odn};
+    s.omA = pfma(cA, dA, s.omA);
+    s.omB = pfma(cB, dB, s.omB);
   }
   // ---- platform extrapolation between manager ticks + bumper contact test ----
   s.mp_xy = pfma(s.mp_uv, bc2(c.dt), s.mp_xy);
-  const bool low = s.p2 - c.bottom <= c.mp_top;
+  const bool low = s.p2 <= (float)c.low_z;
   if (__ballot(low) != 0ull) {  // see platform_contact
     asm volatile("; footprint test" ::: "memory");
     const f2 dxy = s.p01 - s.mp_xy;

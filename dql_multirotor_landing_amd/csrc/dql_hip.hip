@@ -100,6 +100,7 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
   d.dtm = (T)(c.dt / c.mass); d.dtg = (T)(c.dt * c.gravity);
   for (int i = 0; i < 3; ++i) d.dtI[i] = (T)(c.dt / c.inertia[i]);
+  d.nlcd = (T)(-(c.arm_length * c.c_drag)); d.hdt = (T)(0.5 * c.dt); d.low_z = (T)(c.mp_top_z + c.drone_bottom);
   d.oup = (T)(1.0 - c.rotor_alpha_up); d.odn = (T)(1.0 - c.rotor_alpha_down); d.inv_mgr_dt = (T)(1.0 / (c.dt * c.manager_div));
   for (int i = 0; i < 3; ++i) { d.I[i] = (T)c.inertia[i]; d.inv_I[i] = (T)(1.0 / c.inertia[i]); d.kR[i] = (T)c.k_R[i]; d.kW[i] = (T)c.k_W[i]; }
   d.l = (T)c.arm_length; d.h = (T)c.rotor_z; d.kf = (T)c.k_f; d.km = (T)c.k_m; d.lkf = (T)(c.arm_length * c.k_f); d.kmkf = (T)(c.k_m * c.k_f);

@@ -515,6 +515,7 @@ typedef struct {
   REAL dt, g, inv_m, I[3], inv_I[3], l, h, kf, km, lkf, kmkf, aup, adn, omax, cd, crd;
   REAL dtm, dtg, dtI[3]; /* dt / m, dt g, dt / I (float32 tick) */
   REAL oup, odn, inv_mgr_dt; /* 1 - rotor alpha, 1 / manager period (float32 tick) */
+  REAL nlcd, hdt, low_z; /* -(l c_d), dt / 2, mp_top + bottom (float32 tick, round 4b) */
   REAL kR[3], kW[3], ia, ib, ic; /* inverse allocation coefficients */
   pidc_t pvz, pyaw; bwc_t bw;
   REAL mp_dt, mp_top, mp_hx, mp_hy, bottom, z_init, init_sigma, p_max;
@@ -528,6 +529,7 @@ static void simc_init(simc_t* s, const dql_config* c) {
   s->dt = (REAL)c->dt; s->g = (REAL)c->gravity; s->inv_m = (REAL)(1.0 / c->mass);
   s->dtm = (REAL)(c->dt / c->mass); s->dtg = (REAL)(c->dt * c->gravity);
   for (int i = 0; i < 3; ++i) s->dtI[i] = (REAL)(c->dt / c->inertia[i]);
+  s->nlcd = (REAL)(-(c->arm_length * c->c_drag)); s->hdt = (REAL)(0.5 * c->dt); s->low_z = (REAL)(c->mp_top_z + c->drone_bottom);
   s->oup = (REAL)(1.0 - c->rotor_alpha_up); s->odn = (REAL)(1.0 - c->rotor_alpha_down); s->inv_mgr_dt = (REAL)(1.0 / (c->dt * c->manager_div));
   for (int i = 0; i < 3; ++i) { s->I[i] = (REAL)c->inertia[i]; s->inv_I[i] = (REAL)(1.0 / c->inertia[i]); s->kR[i] = (REAL)c->k_R[i]; s->kW[i] = (REAL)c->k_W[i]; }
   s->l = (REAL)c->arm_length; s->h = (REAL)c->rotor_z; s->kf = (REAL)c->k_f; s->km = (REAL)c->k_m;
@@ -658,19 +660,36 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   const REAL* om = e->om; const REAL* w = e->w; const REAL l = s->l, h = s->h;
   /* thrust k_f om_i^2 along body z at rotor i = (+l,0,h), (0,+l,h), (-l,0,h), (0,-l,h); drag torque -dir_i k_m T_i
    * (gazebo_motor_model.cpp:441-452, 476-482; allocation signs pkg/attitude_controller.py:98-104) */
+#if ORACLE_F32
+  /* round 4b: opposite rotors first — sums and differences of the speeds of arm x (0, 2) and arm y (1, 3) serve the thrust torques
+   * (q1 - q3 = (om1 - om3)(om1 + om3)), the drag sums and the total alike; squares by fma: 17 operations instead of 21 (csrc/dql_device.hpp plant_step) */
+  const REAL s02 = om[0] + om[2], s13 = om[1] + om[3], d02 = om[0] - om[2], d13 = om[1] - om[3];
+  const REAL S = s02 + s13;
+  const REAL qa_ = FMA(om[0], om[0], om[2] * om[2]), qb_ = FMA(om[1], om[1], om[3] * om[3]); /* q0 + q2, q1 + q3 */
+  const REAL Fbz = s->kf * (qa_ + qb_);
+  REAL tx = s->lkf * (d13 * s13), ty = -(s->lkf * (d02 * s02)), tz = s->kmkf * (qa_ - qb_);
+#else
   const REAL q0 = om[0] * om[0], q1 = om[1] * om[1], q2 = om[2] * om[2], q3 = om[3] * om[3];
   const REAL Fbz = s->kf * ((q0 + q1) + (q2 + q3));
   REAL tx = s->lkf * (q1 - q3), ty = s->lkf * (q2 - q0), tz = s->kmkf * ((q0 - q1) + (q2 - q3));
+#endif
   /* rotor drag -|om_i| c_d v_perp,i (gazebo_motor_model.cpp:458-469), v_perp,i = (v_body + w x r_i) in the rotor plane,
    * summed over the four rotors in closed form; rolling moment (:484-489) = (c_r / c_d) x the drag force */
   const REAL vbx = FMA(R[0], e->v[0], FMA(R[3], e->v[1], R[6] * e->v[2]));
   const REAL vby = FMA(R[1], e->v[0], FMA(R[4], e->v[1], R[7] * e->v[2]));
   const REAL uxc = FMA(w[1], h, vbx), uyc = FMA(-w[0], h, vby), wzl = w[2] * l;
+#if !ORACLE_F32
   const REAL S = (om[0] + om[1]) + (om[2] + om[3]), d02 = om[0] - om[2], d13 = om[1] - om[3];
+#endif
   const REAL Fbx = -(s->cd * FMA(S, uxc, -(wzl * d13)));
   const REAL Fby = -(s->cd * FMA(S, uyc, wzl * d02));
+#if ORACLE_F32 /* the drag's yaw torque with -(l c_d) as one host constant */
+  tz = FMA(s->nlcd, FMA(uyc, d02, FMA(wzl, S, -(uxc * d13))), tz);
+  tx = FMA(-h, Fby, tx); ty = FMA(h, Fbx, ty);
+#else
   const REAL tzd = -(s->cd * FMA(uyc, d02, FMA(wzl, S, -(uxc * d13))));
   tx = FMA(-h, Fby, tx); ty = FMA(h, Fbx, ty); tz = FMA(l, tzd, tz);
+#endif
   tx = FMA(s->crd, Fbx, tx); ty = FMA(s->crd, Fby, ty);
   /* rotor speed filter (common.h:147-183), commanded speed clipped at max_rot_velocity (gazebo_motor_model.cpp:358-364) */
   for (int i = 0; i < 4; ++i) {
@@ -712,12 +731,21 @@ static inline void motor_and_body(const simc_t* s, env_t* e, const REAL R[9], co
   e->w[1] = FMA(s->dt, (ty - g1) * s->inv_I[1], w[1]);
   e->w[2] = FMA(s->dt, (tz - g2) * s->inv_I[2], w[2]);
 #endif
-  const REAL qw = e->q[0], qx = e->q[1], qy = e->q[2], qz = e->q[3], hdt = R_(0.5) * s->dt;
+  const REAL qw = e->q[0], qx = e->q[1], qy = e->q[2], qz = e->q[3];
+#if ORACLE_F32 /* round 4b: the body rates scaled by dt / 2 once, every component three fmas onto the old one: 15 operations instead of 17 */
+  const REAL h0 = s->hdt * w[0], h1 = s->hdt * w[1], h2 = s->hdt * w[2];
+  const REAL nw = FMA(-qx, h0, FMA(-qy, h1, FMA(-qz, h2, qw)));
+  const REAL nx = FMA(qw, h0, FMA(qy, h2, FMA(-qz, h1, qx)));
+  const REAL ny = FMA(qw, h1, FMA(qz, h0, FMA(-qx, h2, qy)));
+  const REAL nz = FMA(qw, h2, FMA(qx, h1, FMA(-qy, h0, qz)));
+#else
+  const REAL hdt = R_(0.5) * s->dt;
   const REAL dw = -FMA(qx, w[0], FMA(qy, w[1], qz * w[2]));
   const REAL dxq = FMA(qw, w[0], FMA(qy, w[2], -(qz * w[1])));
   const REAL dyq = FMA(qw, w[1], FMA(qz, w[0], -(qx * w[2])));
   const REAL dzq = FMA(qw, w[2], FMA(qx, w[1], -(qy * w[0])));
   const REAL nw = FMA(hdt, dw, qw), nx = FMA(hdt, dxq, qx), ny = FMA(hdt, dyq, qy), nz = FMA(hdt, dzq, qz);
+#endif
   /* renormalise with one Newton step of 1/sqrt(|q|^2) about 1: |q|^2 - 1 = O((dt |w|)^2), so the residual is O(dt^4) */
   const REAL inv = FMA(R_(-0.5), FMA(nw, nw, FMA(nx, nx, FMA(ny, ny, nz * nz))), R_(1.5));
   e->q[0] = nw * inv; e->q[1] = nx * inv; e->q[2] = ny * inv; e->q[3] = nz * inv;
@@ -900,7 +928,11 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
     attitude(s, R, e->w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, M, !s->two_axis);
     motor_and_body(s, e, R, cmd, 1);
     e->mp_x = FMA(e->mp_u, s->dt, e->mp_x); e->mp_y = FMA(e->mp_v, s->dt, e->mp_y);
+#if ORACLE_F32 /* round 4b: altitude test against the host's mp_top + bottom */
+    if (e->p[2] <= s->low_z && FABS(e->p[0] - e->mp_x) <= s->mp_hx && FABS(e->p[1] - e->mp_y) <= s->mp_hy) e->flags |= FL_CONTACT;
+#else
     if (e->p[2] - s->bottom <= s->mp_top && FABS(e->p[0] - e->mp_x) <= s->mp_hx && FABS(e->p[1] - e->mp_y) <= s->mp_hy) e->flags |= FL_CONTACT;
+#endif
   }
   /* euler_from_quaternion, axes sxyz (pkg/landing_simulation_env.py:259-267) */
   quat_to_R(e->q, R);
@@ -1172,7 +1204,11 @@ EXPORT void ORC(plant_run)(const dql_config* c, int64_t n_ticks, const double* i
     quat_to_R(e.q, R);
     motor_and_body(&s, &e, R, cmd, 0);
     e.mp_x = FMA(e.mp_u, s.dt, e.mp_x); e.mp_y = FMA(e.mp_v, s.dt, e.mp_y);
+#if ORACLE_F32
+    if (e.p[2] <= s.low_z && FABS(e.p[0] - e.mp_x) <= s.mp_hx && FABS(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+#else
     if (e.p[2] - s.bottom <= s.mp_top && FABS(e.p[0] - e.mp_x) <= s.mp_hx && FABS(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
+#endif
     double* o = out + t * 20;
     for (int k = 0; k < 3; ++k) { o[k] = e.p[k]; o[3 + k] = e.v[k]; o[10 + k] = e.w[k]; }
     for (int k = 0; k < 4; ++k) { o[6 + k] = e.q[k]; o[13 + k] = e.om[k]; }
