@@ -40,6 +40,10 @@ if __name__ == "__main__":
     ap.add_argument("--eps-tail-after", type=float, default=0.0, help="... from this many episodes per env on")
     ap.add_argument("--recipe", default=None, choices=["bench"], help="bench: the trainer settings of bench.py's curriculum leg (bench.CURRICULUM_KW incl. the population gate, mode paper, sync 16, 768 episodes per env and level)")
     ap.add_argument("--window", type=int, default=100, help="successive_successful_episodes (reference: 100)")
+    ap.add_argument("--as-launched", action="store_true",
+                    help="fly the world the reference's manager node RESOLVED under roslaunch (platform 1 m/s, observation noise 0.25 m / 0.1 m/s: config.AS_LAUNCHED, "
+                         "golden G14) instead of the launch file's literal values (1.6 m/s, no noise)")
+    ap.add_argument("--population-gate", type=float, default=None, help="promotion also needs this success rate of ALL envs (default: the reference's deque alone; --recipe bench: 0.94)")
     a = ap.parse_args()
     import os
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,6 +58,11 @@ if __name__ == "__main__":
         extra = dict(bench.CURRICULUM_KW)
         a.mode, a.sync_period, a.judge_envs = "paper", bench.CURRICULUM_SYNC, extra.pop("judge_envs")
         a.max_episodes = a.max_episodes or bench.CURRICULUM_BUDGET_PER_ENV * a.envs
+    if a.as_launched:
+        from dql_multirotor_landing_amd.config import AS_LAUNCHED
+        extra["env_kw"] = dict(AS_LAUNCHED)
+    if a.population_gate is not None:
+        extra["population_gate"] = a.population_gate
     tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local if world > 1 else None,
                  promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
                  successive_successful_episodes=a.window,
