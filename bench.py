@@ -199,10 +199,12 @@ def spawn_ranks(args, child_argv=None) -> int:
     g.build_hip()  # compile once here (no GPU involved) instead of N times under the lock
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     n = args.gpus
+    import uuid
+    job_id = uuid.uuid4().hex  # per spawn: ranks respawned by this parent on the same port never accept an earlier spawn's bootstrap file (comm.py)
     procs, out0 = [], tempfile.TemporaryFile(mode="w+")
     errs = [sys.stderr] + [tempfile.TemporaryFile(mode="w+") for _ in range(1, n)]  # ranks != 0 are heard only when the job fails
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DQL_COMM_JOB_ID=job_id)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(child_argv or [sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=out0 if r == 0 else errs[r], stderr=errs[r]))

@@ -104,6 +104,11 @@ SYMBOLS = {
     "dql_mdp_transition": (C.c_int, [_cfgp, C.c_int, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dql_manager_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _u64, _vp]),
     "dql_plant_run": (C.c_int, [_cfgp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "dql_butterworth_run": (C.c_int, [_cfgp, C.c_int, _vp, _i64, _vp]),
+    "dql_kalman_run": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
+    "dql_pid_run": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
+    "dql_attitude_run": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "dql_platform_run": (C.c_int, [_cfgp, C.c_int, _i64, _i32, _vp]),
     "dql_selftest_sqrt": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_i64)]),
     "dql_place": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
     "dql_agent_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),

@@ -12,7 +12,9 @@ counts the communicators a process has created (every rank creates them in the s
 atomically (temp + rename) and removes it when the communicator is closed.  An explicit $DQL_COMM_ID_FILE has no such nonce
 in its name, so every bootstrap file also carries one INSIDE: a 24-byte header (magic, MASTER_PORT, WORLD_SIZE, 12 bytes of job nonce).
 The nonce is a hash of $DQL_COMM_JOB_ID when the launcher sets one (ranks that do not share a parent: mpirun, srun), else of
-$TORCHELASTIC_RUN_ID + the parent's (pid, start time) — the same for every rank of a job, different for any other job, whenever it runs.
+$TORCHELASTIC_RUN_ID + $TORCHELASTIC_RESTART_COUNT + the parent's (pid, start time) — the same for every rank of a job, different for any other
+job and for any other ATTEMPT of an elastic job, whenever it runs.  A parent that respawns its ranks itself on the same port must hand every
+spawn a fresh $DQL_COMM_JOB_ID (bench.py's spawn_ranks does: a uuid4 per spawn).
 A reader accepts a file with its own job's header only: what a killed job left behind — even one relaunched seconds later on the same
 port — is polled past, however old or young it is, and a rank that starts minutes after rank 0 still finds rank 0's file valid.
 Rank 0 removes whatever sits under the name before it creates its communicator.
@@ -41,7 +43,10 @@ def _job_nonce() -> bytes:
     """12 bytes every rank of THIS job computes alike and no other job does (module docstring)"""
     import hashlib
     job = os.environ.get("DQL_COMM_JOB_ID")
-    key = f"job:{job}" if job else f"run:{os.environ.get('TORCHELASTIC_RUN_ID', '')}|parent:{_parent_token()}"
+    # TORCHELASTIC_RESTART_COUNT: an elastic restart keeps the agent (the parent), the run id and — with static rendezvous — the port; without it the
+    # workers of attempt k + 1 would compute attempt k's nonce and could pick up the dead attempt's unique id before rank 0 has replaced it
+    key = (f"job:{job}" if job else
+           f"run:{os.environ.get('TORCHELASTIC_RUN_ID', '')}|restart:{os.environ.get('TORCHELASTIC_RESTART_COUNT', '')}|parent:{_parent_token()}")
     return hashlib.sha256(key.encode()).digest()[:12]
 
 

@@ -267,6 +267,7 @@ template <typename T> struct SimK {
   T p_max, theta_max, delta_theta, z_init, init_sigma;  // reset placement / set-point update (before the loop)
   int div, traj, init_uniform, working, per_env_platform, two_axis;
   uint32_t quirks;
+  int noisy, kal_r_zero;  // noise_p > 0 || noise_v > 0; kal_r == 0 (host: make_simk) — the wave-uniform branches on them read these, not the floats
 };
 
 // Per-tick constants held in VECTOR registers for the duration of the tick loop.  The loop wants ~50 constants on top of its
@@ -297,6 +298,23 @@ DQL_DEV HotK<float> make_hot(const SimK<float>& s) {
   return h;
 }
 
+// ROUND 5.  The constants of the 100 Hz manager tick and of the period's begin / end (noise, Kalman, platform step, reset placement, set-point
+// update) are kernel arguments: wave-uniform, so the compiler keeps them in SGPRs — of which the step kernel has none to spare (it sits at the
+// 102-register cap), so it REMATERIALISES them from the kernarg segment wherever they are used: `s_load_dword sN, s[0:1], off` followed a few
+// instructions later by `s_waitcnt lgkmcnt(0)`, five times per manager tick, twice per physics tick (the two PID set-points), a dozen times
+// per period — ~70 scalar loads per wave and period, each parking the wave for a scalar-cache round trip.  At two waves per SIMD nobody fills
+// the gap: SQ_WAIT_ANY was 18 % of the wave cycles (profiles/r5_pmc_wave_cycles_before.json).  A VALU operand may just as well be a VGPR, and at
+// <= 2 waves per SIMD the kernel has ~90 of them to spare: one opaque v_mov per constant before the period loop, and the compiler has nothing
+// to rematerialise.  Wave-uniform BRANCHES on these values read the host's ints (SimK::noisy, kal_r_zero) instead.
+template <typename T> DQL_DEV SimK<T> period_consts_in_vgprs(SimK<T> c) { return c; }
+template <> DQL_DEV SimK<float> period_consts_in_vgprs<float>(SimK<float> c) {
+#define DQL_V(f) c.f = to_vgpr(c.f)
+  DQL_V(noise_p); DQL_V(noise_v); DQL_V(kal_q); DQL_V(kal_r); DQL_V(mgr_dt); DQL_V(inv_mgr_dt); DQL_V(mp_dt); DQL_V(kal_pss); DQL_V(kal_kss);
+  DQL_V(p_max); DQL_V(theta_max); DQL_V(delta_theta); DQL_V(z_init); DQL_V(init_sigma); DQL_V(mp_r); DQL_V(mp_w); DQL_V(vz_sp); DQL_V(yw_sp);
+#undef DQL_V
+  return c;
+}
+
 // The same constants as instruction LITERALS, for the reference vehicle (dql_refk.inc, generated by tools/gen_refk.py): a literal costs
 // neither a register nor an SGPR operand (which halves a VALU instruction's issue rate beside other waves,
 // profiles/r2_pk_variants.jsonl).  The host selects this variant only when the context's SimK is bit-identical to the table.
@@ -309,6 +327,26 @@ struct LitK {
   DQL_REFK_VECTORS(DQL_A)
 #undef DQL_A
   float vz_sp, yw_sp;  // per-config set-points (training -0.1 m/s, simulation env -0.4): stay run-time values
+};
+
+// ROUND 5: the reference MDP's constants (pkg/mdp.py:87-147: limits, weights, angle grid, normalisers) as instruction literals too.  MdpK is ~60
+// values; read as scalars at the end of every period they evict everything else from the SGPR file (and every evicted kernel argument comes back
+// as an s_load + wait), read as vectors they cost twelve loads per lane.  As literals they cost nothing, and sel5 / latest_valid_level fold on
+// known limits.  What a run changes stays a kernel argument (MdpRun): working level and quirks (SimK has them), goal logic, time-out steps = t_max f_ag,
+// gamma.  Selected by the host together with LitK, only when make_mdpk(cfg) equals the table bit for bit (dql_hip.hip refm_matches).
+template <typename T> struct MdpRun { double gamma; T timeout_steps; int goal_logic; };
+struct LitM {
+#define DQL_X(n, v) static constexpr float n = v;
+  DQL_REFM_SCALARS(DQL_X)
+#undef DQL_X
+#define DQL_L(n, a, b, c, d, e) static constexpr float n[5] = {a, b, c, d, e};
+  DQL_REFM_LIMITS(DQL_L)
+  DQL_REFM_RATIOS(DQL_L)  // ratio_p / ratio_v[k] = lim[k + 1] / lim[k], divided on the build host (correctly rounded float32)
+#undef DQL_L
+#define DQL_G(n, a, b, c, d, e, f, g) static constexpr float n[7] = {a, b, c, d, e, f, g};
+  DQL_REFM_GRID(DQL_G)
+#undef DQL_G
+  float timeout_steps; double gamma; int working, goal_logic; uint32_t quirks;
 };
 
 enum { FL_DONE = 1, FL_CONTACT = 2, FL_ACC_INIT = 4, FL_WAS_RESET = 8, FL_OBS_CONTACT = 16 };
@@ -362,7 +400,8 @@ template <typename T> DQL_DEV T norm_by(T x, T d, T inv) {
   if constexpr (sizeof(T) == 4) return x * inv;
   else return x / d;
 }
-template <typename T> DQL_DEV int discretise(const MdpK<T>& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
+// M: MdpK<T> (run-time constants) or LitM (the reference MDP as literals, float32)
+template <typename M, typename T> DQL_DEV int discretise(const M& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
   const T cp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
   const T cv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T ca = clip(norm_by(rel_a, m.a_max, m.inv_a_max), T(-1.0), T(1.0));
@@ -373,16 +412,17 @@ template <typename T> DQL_DEV int discretise(const MdpK<T>& m, T rel_p, T rel_v,
   k = ka < k ? ka : k;
   const T lp = sel5(m.lim_p, k), lv = sel5(m.lim_v, k), la = sel5(m.lim_a, k);
   T pc = m.beta, vc = m.beta, ac = m.sigma_a;
-  if (k < m.working) { pc = sel5(m.lim_p, k + 1) / lp; vc = sel5(m.lim_v, k + 1) / lv; }
-  if (k == m.working) ac = ac * m.beta;
+  if constexpr (__is_same(M, LitM)) { if (k < m.working) { pc = sel5(m.ratio_p, k); vc = sel5(m.ratio_v, k); } }  // the same quotients, divided on the build host (tools/gen_refk.py)
+  else if (k < m.working) { pc = sel5(m.lim_p, k + 1) / lp; vc = sel5(m.lim_v, k + 1) / lv; }
+  if (k == m.working) ac = ac * T(m.beta);
   const int dp = disc3(cp, lp * pc, lp);
   const int dv = disc3(cv, lv * vc, lv);
   const int da = disc3(ca, la * ac, la);
   if (dp < 0 || dv < 0 || da < 0) return -1;
-  const T ct = clip(angle, -m.theta_max, m.theta_max);
-  int best = 0; T bd = abs_(m.angles[0] - ct);
+  const T ct = clip(angle, -T(m.theta_max), T(m.theta_max));
+  int best = 0; T bd = abs_(T(m.angles[0]) - ct);
 #pragma unroll
-  for (int i = 1; i < 7; ++i) { const T d = abs_(m.angles[i] - ct); if (d < bd) { bd = d; best = i; } }
+  for (int i = 1; i < 7; ++i) { const T d = abs_(T(m.angles[i]) - ct); if (d < bd) { bd = d; best = i; } }
   return (((k * 3 + dp) * 3 + dv) * 3 + da) * 7 + best;
 }
 DQL_DEV int idx_level(int idx) { return idx / DQL_STATES_PER_LEVEL; }
@@ -394,8 +434,8 @@ template <typename T, typename K> DQL_DEV T continuous_action(const K& m, T sp, 
   if (action == 1) { const T t = sp - m.delta_theta; return t > -m.theta_max ? t : -m.theta_max; }
   return sp;
 }
-template <typename T>
-DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
+template <typename M, typename T>
+DQL_DEV int mdp_check(const M& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
                       T rel_p_y, T abs_p_z, bool two = false, int prev_idy = -1, int cur_idy = -1) {  // :335-439
   // two-axis configs (beyond the reference, B16): the goal state is the joint goal of both 1-D MDPs
   const bool goal_x = prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1;
@@ -422,8 +462,8 @@ DQL_DEV int mdp_check(const MdpK<T>& m, int& step_count, int& cur_check, int cod
   }
   return code;
 }
-template <typename T>
-DQL_DEV T mdp_reward(const MdpK<T>& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
+template <typename M, typename T>
+DQL_DEV T mdp_reward(const M& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
   const T ncp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
   const T ncv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T npitch = norm_by(angle_sp, m.theta_max, m.inv_theta_max);
@@ -533,13 +573,14 @@ DQL_DEV T pid_output(const K& c, T kp, T ki, T lo, T hi, T wind, T sp, T state, 
 // env sits ON the fixed point, bit for bit, and the update would recompute the same K and the same P at every 100 Hz tick — two additions, a
 // correctly rounded division (ten instructions), a subtraction and a multiplication.  When every lane of the wave is there they are skipped:
 // the same values by construction, so the oracle keeps the plain update.
-template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z, T pss = T(-1.0), T kss = T(0.0)) {  // filters.py:19-36
+// r_zero: R == 0, decided by the caller from the kernel argument itself (wave-uniform scalar branch): Rm may be a VGPR copy here (period_consts_in_vgprs)
+template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z, T pss, T kss, bool r_zero) {  // filters.py:19-36
   if (__ballot(!(P == pss)) == 0ull) {
     x += kss * (z - x);
     return x;
   }
   P += Q;
-  if (Rm == T(0.0)) {  // wave-uniform (launch files: no measurement noise): P / (P + 0) is exactly 1, no division to pay for
+  if (r_zero) {  // wave-uniform (launch files: no measurement noise): P / (P + 0) is exactly 1, no division to pay for
     x += (z - x);
     P *= T(0.0);
     return x;
@@ -549,6 +590,7 @@ template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z, T pss = T(-
   P *= (T(1.0) - K);
   return x;
 }
+template <typename T> DQL_DEV T kalman1d(T& x, T& P, T Q, T Rm, T z, T pss = T(-1.0), T kss = T(0.0)) { return kalman1d(x, P, Q, Rm, z, pss, kss, Rm == T(0.0)); }
 
 // ---------------------------------------------------------------------------------------------
 // simulator pieces
@@ -850,7 +892,7 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
   const T rpx = fma_(cy, dxw, sy * dyw), rpy = fma_(cy, dyw, -(sy * dxw));
   const T rvx = fma_(cy, dvx, sy * dvy), rvy = fma_(cy, dvy, -(sy * dvx));
   T opx = rpx, opy = rpy, ovx = rvx, ovy = rvy;
-  if (with_noise && (s.noise_p > T(0.0) || s.noise_v > T(0.0))) {
+  if (with_noise && s.noisy) {
     uint32_t r[4]; T n0, n1, n2, n3;
     philox4x32(step_lo, step_hi, env_id, STREAM_NOISE0 + mgr_in_step, k0, k1, r);
     box_muller(r[0], r[1], n0, n1); box_muller(r[2], r[3], n2, n3);
@@ -865,11 +907,11 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
     else dt_ = s.mgr_dt;
     if (dt_ <= T(0.0)) dt_ = T(0.01);
     if (Fast32<T>::on && !(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) {  // constant divisor: one multiplication (float32 tick)
-      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) * s.inv_mgr_dt, s.kal_pss, s.kal_kss);
-      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) * s.inv_mgr_dt, s.kal_pss, s.kal_kss);
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) * s.inv_mgr_dt, s.kal_pss, s.kal_kss, s.kal_r_zero != 0);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) * s.inv_mgr_dt, s.kal_pss, s.kal_kss, s.kal_r_zero != 0);
     } else {
-      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_, s.kal_pss, s.kal_kss);
-      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_, s.kal_pss, s.kal_kss);
+      ax_ = kalman1d(e.kal_x_x, e.kal_x_P, s.kal_q, s.kal_r, (rvx - e.vf_x) / dt_, s.kal_pss, s.kal_kss, s.kal_r_zero != 0);
+      if (s.two_axis) ay_ = kalman1d(e.kal_y_x, e.kal_y_P, s.kal_q, s.kal_r, (rvy - e.vf_y) / dt_, s.kal_pss, s.kal_kss, s.kal_r_zero != 0);
     }
     if (!(s.quirks & DQL_Q_FROZEN_ACC_REFERENCE)) { e.vf_x = rvx; if (s.two_axis) e.vf_y = rvy; }
   }
@@ -1111,6 +1153,16 @@ DQL_DEV void physics_tick_pk(const K& c, const PkK& k, TickPk& s, const RotPk& r
   }
 }
 
+// double -> int64 fixed point, round to nearest even: llrint() for |x| <= 2^50, saturating beyond (a TD target of 2^24 = 16.7 M in units of reward; the
+// accumulators would overflow long before).  The 2^52 trick: x + 1.5 * 2^52 lands in [2^52, 2^53), where one ulp is 1, so the mantissa IS the rounded
+// integer and the difference of the bit patterns its value — 2 double-precision clamps, 1 addition, 1 64-bit subtraction instead of the ~25
+// instructions of a generic double -> int64 conversion, twice per env-step.  The oracle saturates the same way (oracle/dql_oracle.c fx_round).
+DQL_DEV long long fx_round(double x) {
+  x = __builtin_fmin(__builtin_fmax(x, -0x1p50), 0x1p50);
+  const double t = x + 0x1.8p52;
+  return __double_as_longlong(t) - __double_as_longlong(0x1.8p52);
+}
+
 struct StepOut {  // what one env contributes to the shared tables / counters this period
   long long target_fx;  // TD target, fixed point (DQL_TARGET_FRAC_BITS)
   long long target_y_fx;
@@ -1129,7 +1181,7 @@ struct PeriodCtx {
 // Start of an agent period: reset placement (landing_simulation_env.py:167-243) or eps-greedy guess + set-point update
 // (double_q_learning.py:110-117, mdp.py:543-560).  TabPtr: pointer to the (read-only) acting Q tables.
 template <typename T, typename TabPtr>
-DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps, int ext_action, uint64_t seed,
+DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr, int ext_action, uint64_t seed,
                                uint32_t env_id, long long step_index) {
   PeriodCtx c;
   c.k0 = (uint32_t)seed; c.k1 = (uint32_t)(seed >> 32); c.step_lo = (uint32_t)step_index; c.step_hi = (uint32_t)((uint64_t)step_index >> 32);
@@ -1165,11 +1217,12 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
     if (mode == MODE_EXTERNAL) { action = ext_action & 3; action_y = two ? (ext_action >> 2) & 3 : 2; }
     else {
       const int greedy = agent_predict(qx);  // row of prev_idx, requested together with the env state
-      const bool explore = (mode == MODE_TRAIN) && ((double)u24<T>(r[0]) < eps);
+      // u24(r) < eps with u24(r) = (r >> 8) 2^-24: the same comparison among integers, (r >> 8) < ceil(eps 2^24) (host: eps_threshold)
+      const bool explore = (mode == MODE_TRAIN) && ((r[0] >> 8) < eps_thr);
       action = explore ? (int)(((uint64_t)r[1] * 3u) >> 32) : greedy;
       if (two) {
         const int greedy_y = agent_predict(qa, qb, c.prev_idy < 0 ? 0 : c.prev_idy);
-        const bool explore_y = (mode == MODE_TRAIN) && ((double)u24<T>(r2[0]) < eps);
+        const bool explore_y = (mode == MODE_TRAIN) && ((r2[0] >> 8) < eps_thr);
         action_y = explore_y ? (int)(((uint64_t)r2[1] * 3u) >> 32) : greedy_y;
       }
     }
@@ -1186,19 +1239,34 @@ DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabP
 // of the three choices inside ONE run (all / none / this) shows no time difference beyond 0.5 % at 4 096 ... 1 M envs — differences between
 // runs on different boxes are 2-3 % and had looked like an effect; what it does buy is registers: 14 VGPRs less in the multi-wave layouts, and
 // the 128-VGPR variant's scratch 164 -> 92 B per lane.  The lone-wave layouts (registers to spare) keep the plain pointer.
-template <bool SCALAR_MDP, typename T, typename TabPtr>
-DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
+// MDP_SRC: where the MDP constants come from — MDP_VECTOR / MDP_SCALAR: the MdpK buffer, with vector or scalar loads; MDP_LITERAL: LitM + MdpRun
+enum { MDP_VECTOR = 0, MDP_SCALAR = 1, MDP_LITERAL = 2 };
+template <typename T, typename M, typename TabPtr>
+DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode);
+template <int MDP_SRC, typename T, typename TabPtr>
+DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, const MdpRun<T>& mr, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
+  if constexpr (MDP_SRC == MDP_LITERAL && sizeof(T) == 4) {
+    const LitM m{mr.timeout_steps, mr.gamma, s.working, mr.goal_logic, s.quirks};
+    return period_end_with(s, m, e, c, qa, qb, mode);
+  } else {
+    asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the tick loop
+    MdpK<T> m;
+    if constexpr (MDP_SRC == MDP_SCALAR) __builtin_memcpy(&m, mp, sizeof(m));
+    else m = *(const MdpK<T>*)mp;
+    return period_end_with(s, m, e, c, qa, qb, mode);
+  }
+}
+template <typename T, typename M, typename TabPtr>
+DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const PeriodCtx& c, TabPtr qa, TabPtr qb, int mode) {
   StepOut out; out.cell = -1; out.cell_y = -1; out.decision = 0; out.done = 0; out.target_fx = 0; out.target_y_fx = 0; out.reward_fx = 0;
   const bool two = s.two_axis != 0;
   const int prev_idx = c.prev_idx, prev_idy = c.prev_idy;
-  asm volatile("" ::: "memory");  // keep the MdpK scalar loads below the tick loop
-  MdpK<T> m;
-  if constexpr (SCALAR_MDP) __builtin_memcpy(&m, mp, sizeof(m));
-  else m = *(const MdpK<T>*)mp;
   T R[9];
+  DQL_SECTION("end_pitch");
   quat_to_R(e.q, R);
   const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
   const T pitch = det_atan2(-R[6], cyy);
+  DQL_SECTION("end_discretise");
   int idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
   if (idx < 0) idx = 0;
   e.idx_x = idx;
@@ -1212,21 +1280,25 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env
   e.reward = T(0.0);
   // both tables' row of the new state, requested as soon as the index exists: check / reward below run while it travels, the TD target
   // takes it from registers, and so does the NEXT period's greedy choice when the env stays in registers (periods_per_launch > 1)
+  DQL_SECTION("end_qrow");
   out.next = load_qrow(qa, qb, idx);
   DQL_MARK_T(e, 41);
   if (c.is_reset) return out;
+  DQL_SECTION("end_check");
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
   e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
+  DQL_SECTION("end_reward");
   const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
   T rew_y = T(0.0);
   if (two) rew_y = mdp_reward(m, e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y, e.code, idy, e.obs_py, e.obs_vy, -e.roll_sp);
   e.reward = two ? rew + rew_y : rew;
   DQL_MARK_T(e, 42);
+  DQL_SECTION("end_target");
   const bool done = e.code <= DQL_TERMINAL_TIMEOUT;
   if (done) e.flags |= FL_DONE;
   out.decision = 1; out.done = done ? 1 : 0;
-  out.reward_fx = __double2ll_rn((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
-  if (two) out.reward_fx += __double2ll_rn((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  out.reward_fx = fx_round((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  if (two) out.reward_fx += fx_round((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (mode == MODE_TRAIN) {
     // Reference (B1/B2, DQL_Q_UPDATE_TABLE_A_ONLY): always Q_table_a, valued by itself.  Otherwise Double Q-learning as the paper
     // has it: the coin picks the table to update, the OTHER table values the picked table's greedy action at s'.
@@ -1247,7 +1319,7 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env
       else mask = !done;
       const double target = (double)rew + (m.gamma * boot) * (double)mask;
       out.cell = prev_idx * 3 + c.action + (sel_b ? DQL_N_CELLS : 0);
-      out.target_fx = __double2ll_rn(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      out.target_fx = fx_round(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
     }
     if (two) {  // the y transition updates the same shared tables
       const bool sel_b = dbl && c.coin_y;
@@ -1265,7 +1337,7 @@ DQL_DEV StepOut period_end(const SimK<T>& s, const MdpK<T> DQL_CONST_AS* mp, Env
       else mask_y = !done;
       const double target_y = (double)rew_y + (m.gamma * boot_y) * (double)mask_y;
       out.cell_y = prev_idy * 3 + c.action_y + (sel_b ? DQL_N_CELLS : 0);
-      out.target_y_fx = __double2ll_rn(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      out.target_y_fx = fx_round(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
     }
   }
   return out;
@@ -1308,11 +1380,14 @@ template <int TICK, typename T> struct TickConsts {
 // constant 0); X_RUNTIME: decided by s.two_axis (wave-uniform), both forms in the code — the layouts the host does not pick by itself.
 enum { X_TWO = 0, X_ONLY = 1, X_RUNTIME = 2 };
 template <int TICK, int XMODE, typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, double eps,
-                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long g0, int n_ticks) {
-  const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps, ext_action, seed, env_id, step_index);
+DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, const MdpRun<T>& mr, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr,
+                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long mgr0, int sched) {
+  DQL_SECTION("period_begin");
+  const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps_thr, ext_action, seed, env_id, step_index);
   T B[9];
+  DQL_SECTION("make_B");
   make_B(e.pitch_sp, e.roll_sp, B);
+  DQL_SECTION("tick_setup");
   constexpr bool HOT = TICK == TICK_LONE || TICK == TICK_PACKED;
   const auto& h = tc.h;
   DQL_MARK_T(e, 3);
@@ -1321,11 +1396,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   uint32_t mgr_in_step = 0;
   PlatRec<T> prec;                      // platform sine / cosine carried between the manager ticks of this period (float32: platform_update)
   prec = PlatRec<T>{};
-  int phase = (int)(g0 % s.div);        // physics ticks since the last 100 Hz manager tick (wave-uniform)
-  long long mgr_index = g0 / s.div + (phase ? 1 : 0);  // index of the next manager tick
-  // the period's last manager tick (wave-uniform): the only one whose observation noise is ever read (manager_obs)
-  const int first_mgr = phase ? s.div - phase : 0;
-  const uint32_t last_mgr = first_mgr < n_ticks ? (uint32_t)((n_ticks - 1 - first_mgr) / s.div) : 0u;
+  // the period's tick schedule, derived on the host from the global tick count (make_step_args; wave-uniform): its physics ticks, the ticks since
+  // the last 100 Hz manager tick, the index of the next manager tick, and the period's LAST manager tick — the only one whose observation noise
+  // is ever read (manager_obs)
+  const int n_ticks = sched & 0xff;
+  int phase = (sched >> 8) & 0xff;
+  long long mgr_index = mgr0;
+  const uint32_t last_mgr = (uint32_t)(sched >> 16);
   auto manager_tick = [&]() {
     DQL_SECTION("manager");
     DQL_PHASE(e, 2);
@@ -1447,11 +1524,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   DQL_MARK_T(e, 4);
   DQL_PHASE(e, 2);
 #if defined(DQL_SCALAR_MDP_ALL)   // A/B builds (tools/ab_build.sh)
-  const StepOut o = period_end<true>(s, mp, e, c, qa, qb, mode);
+  const StepOut o = period_end<MDP_SCALAR>(s, mp, mr, e, c, qa, qb, mode);
 #elif defined(DQL_SCALAR_MDP_NONE)
-  const StepOut o = period_end<false>(s, mp, e, c, qa, qb, mode);
+  const StepOut o = period_end<MDP_VECTOR>(s, mp, mr, e, c, qa, qb, mode);
+#elif defined(DQL_AB_NO_LITERAL_MDP)
+  const StepOut o = period_end<HOT ? MDP_VECTOR : MDP_SCALAR>(s, mp, mr, e, c, qa, qb, mode);
 #else
-  const StepOut o = period_end<!HOT>(s, mp, e, c, qa, qb, mode);
+  const StepOut o = period_end<TICK == TICK_LIT ? MDP_LITERAL : (HOT ? MDP_VECTOR : MDP_SCALAR)>(s, mp, mr, e, c, qa, qb, mode);
 #endif
   DQL_MARK_T(e, 5);
   DQL_PHASE(e, 4);

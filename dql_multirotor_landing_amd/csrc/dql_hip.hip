@@ -75,13 +75,31 @@ static bool refk_matches(const SimK<float>& s) {
 #undef DQL_A
   return ok;
 }
+// ... and is this MdpK the table LitM was compiled with?  (the run-time members — working, goal_logic, quirks, timeout_steps, gamma — are not part of it)
+static bool refm_matches(const MdpK<float>& m) {
+  bool ok = true;
+#define DQL_X(n, v) { const float r = v; ok = ok && memcmp(&m.n, &r, sizeof(float)) == 0; }
+  DQL_REFM_SCALARS(DQL_X)
+#undef DQL_X
+  for (int k = 0; k < 4; ++k) {  // the quotient tables are what discretise() would divide at run time
+    volatile float qp = m.lim_p[k + 1] / m.lim_p[k], qv = m.lim_v[k + 1] / m.lim_v[k];
+    const float rp = LitM::ratio_p[k], rv = LitM::ratio_v[k];
+    ok = ok && memcmp((const void*)&qp, &rp, sizeof(float)) == 0 && memcmp((const void*)&qv, &rv, sizeof(float)) == 0;
+  }
+#define DQL_L(n, a, b, c, d, e) { const float r[5] = {a, b, c, d, e}; ok = ok && memcmp(m.n, r, sizeof(r)) == 0; }
+  DQL_REFM_LIMITS(DQL_L)
+#undef DQL_L
+#define DQL_G(n, a, b, c, d, e, f, g) { const float r[7] = {a, b, c, d, e, f, g}; ok = ok && memcmp(m.n, r, sizeof(r)) == 0; }
+  DQL_REFM_GRID(DQL_G)
+#undef DQL_G
+  return ok;
+}
 // P's fixed point under kalman1d's update in T arithmetic (P += Q; K = P / (P + R); P *= 1 - K), reached from the creation value P = 1; pss = NaN when
 // the iteration does not settle on one value (then the kernel's shortcut never fires).  R = 0: kalman1d's own shortcut applies, no fixed point needed.
+// A context computes it ONCE (dql_create; the noise constants of a context never change) and hands it to make_simk with every launch: a (Q, R) that
+// settles on a 2-cycle costs its 200 000 iterations once, not per launch, and contexts with different noise settings do not evict each other.
 template <typename T> static void kalman_fixed_point(T Q, T R, T& pss, T& kss) {
-  static thread_local T memo_q = T(-1), memo_r = T(-1), memo_p = T(0), memo_k = T(0);  // make_simk runs once per launch: remember the last answer
-  if (Q == memo_q && R == memo_r) { pss = memo_p; kss = memo_k; return; }
   pss = std::numeric_limits<T>::quiet_NaN(); kss = T(0);
-  memo_q = Q; memo_r = R; memo_p = pss; memo_k = kss;
   if (!(R > T(0)) || !(Q >= T(0))) return;
   volatile T P = T(1);
   for (int i = 0; i < 200000; ++i) {
@@ -90,11 +108,12 @@ template <typename T> static void kalman_fixed_point(T Q, T R, T& pss, T& kss) {
     volatile T K = P1 / den;
     volatile T om = T(1) - K;
     volatile T P2 = P1 * om;
-    if (P2 == P) { pss = P; kss = K; memo_p = pss; memo_k = kss; return; }
+    if (P2 == P) { pss = P; kss = K; return; }
     P = P2;
   }
 }
-template <typename T> static SimK<T> make_simk(const dql_config& c) {
+struct KalFix { double pss, kss; bool valid; };  // the fixed point in the context's dtype, widened (exact)
+template <typename T> static SimK<T> make_simk(const dql_config& c, const KalFix* kf = nullptr) {
   SimK<T> d;
   memset(&d, 0, sizeof(d));
   d.dt = (T)c.dt; d.g = (T)c.gravity; d.inv_m = (T)(1.0 / c.mass);
@@ -114,12 +133,14 @@ template <typename T> static SimK<T> make_simk(const dql_config& c) {
   d.mp_dt = (T)c.mp_dt; d.mp_top = (T)c.mp_top_z; d.mp_hx = (T)c.mp_half_x; d.mp_hy = (T)c.mp_half_y; d.bottom = (T)c.drone_bottom;
   d.noise_p = (T)c.noise_pos_sd; d.noise_v = (T)c.noise_vel_sd; d.kal_q = (T)c.kalman_q; d.kal_r = (T)(c.noise_vel_sd * c.noise_vel_sd);
   d.mgr_dt = (T)(c.dt * c.manager_div);
-  kalman_fixed_point<T>(d.kal_q, d.kal_r, d.kal_pss, d.kal_kss);
+  if (kf && kf->valid) { d.kal_pss = (T)kf->pss; d.kal_kss = (T)kf->kss; }
+  else kalman_fixed_point<T>(d.kal_q, d.kal_r, d.kal_pss, d.kal_kss);
   d.mp_r = (T)c.mp_r_x; d.mp_w = (T)(c.mp_t_x / c.mp_r_x);
   if (c.trajectory == DQL_TRAJ_EIGHT) { d.mp_r = (T)3.0; d.mp_w = (T)(0.8 / 3.0); }
   d.p_max = (T)c.p_max; d.theta_max = (T)c.theta_max; d.delta_theta = (T)c.delta_theta; d.z_init = (T)c.z_init; d.init_sigma = (T)c.init_sigma;
   d.div = c.manager_div; d.traj = c.trajectory; d.init_uniform = c.init_uniform; d.working = c.working_curriculum_step;
   d.per_env_platform = c.per_env_platform; d.two_axis = c.two_axis; d.quirks = c.quirks;
+  d.noisy = (d.noise_p > T(0) || d.noise_v > T(0)) ? 1 : 0; d.kal_r_zero = (d.kal_r == T(0)) ? 1 : 0;
   return d;
 }
 
@@ -213,6 +234,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T> DQL_CONST_AS* mdp;  // device buffer, read as constant memory (scalar loads)
+  MdpRun<T> mdp_run;                // what the literal-constant layout still needs at run time (dql_device.hpp LitM)
   Quad<T>* sr; int4* si;
   const double* qa; const double* qb;  // ACTING tables of this launch: every accumulator up to launch j-2 folded in
   unsigned long long* acc_cur;         // [2][DQL_N_CELLS] of this launch: target sums (fixed point), visits
@@ -224,10 +246,13 @@ template <typename T> struct StepArgs {
   const uint8_t* actions;
   unsigned long long* elog;            // episode log rows of this launch or null: per period [n_waves] done masks, [n_waves] success masks
   long long n, env_id_offset, step_index;  // step_index: the first agent period of this launch
-  long long g0[DQL_MAX_PERIODS];           // physics ticks elapsed before each period of the launch
+  // per period of the launch, from the host (round 5: the kernel used to derive them from the tick count g0 with a 64-bit division and a modulo per
+  // wave and period): index of the period's first manager tick, and in sched[p] its physics ticks | ticks since the last manager tick << 8 |
+  // index of the period's LAST manager tick (the one whose noise is read) << 16
+  long long mgr0[DQL_MAX_PERIODS];
   unsigned long long seed;
-  double eps;
-  int n_ticks[DQL_MAX_PERIODS];
+  unsigned int eps_thr, pad_;  // explore <=> (r >> 8) < eps_thr: ceil(eps 2^24), the integer form of u24(r) < eps (host: eps_threshold)
+  int sched[DQL_MAX_PERIODS];
   int mode, n_periods, env_blocks, have_prev, windowed;
 };
 
@@ -252,7 +277,7 @@ DQL_DEV long long wave_sum(long long v) {
 template <int BYTES> DQL_DEV void warm_kernarg() {
   const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
   constexpr int L = (BYTES + 63) / 64;  // 64-byte lines the arguments reach (9 .. 17); offsets beyond the last line fold back onto it (a 17th line — float64 — is left to its first use)
-  static_assert(L > 8 && L <= 17, "adjust the touch list to the argument size");
+  static_assert(L > 8 && L <= 18, "adjust the touch list to the argument size");  // (sixteen lines are touched: float64's 17th and 18th are left to their first use)
 #define DQL_LINE(i) ((i) < L ? (i) * 64 : (L - 1) * 64)
   unsigned t0, t1, t2, t3, t4, t5, t6, t7, u0, u1, u2, u3, u4, u5, u6, u7;
   // sixteen loads in flight, one wait.  The first statement's destinations are inputs of the second, so the compiler keeps them allocated
@@ -343,6 +368,10 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
   // XMODE (dql_device.hpp agent_period): in an x-axis kernel the config's two_axis is the constant 0 — every y-axis branch of the step folds away
   SimK<T> cfgk = a.c;
   if constexpr (XMODE == X_ONLY) cfgk.two_axis = 0;
+  // register headroom (<= 2 waves per SIMD: 256 VGPRs): the manager tick's and the period's run-time constants move to VGPRs once per launch
+#ifndef DQL_AB_NO_VGPR_CONSTS  // A/B builds (tools/ab_build.sh)
+  if constexpr (sizeof(T) == 4 && BLOCK < 512) cfgk = period_consts_in_vgprs(cfgk);
+#endif
   const TickConsts<TICK, T> tc(cfgk);
   for (int p = 0; p < a.n_periods; ++p) {
     dec = 0; don = 0; rfx = 0; goal = false;
@@ -353,7 +382,8 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
         const int ax = ext & 3, ay = (ext >> 2) & 3;
         if (ax > 2 || ay > 2 || (ext >> 4) || (!a.c.two_axis && ay != 0 && ay != 2)) atomicAdd(&a.stats->bad_actions, 1ull);
       }
-      const StepOut o = agent_period<TICK, XMODE>(cfgk, tc, a.mdp, e, qx, a.qa, a.qb, a.mode, a.eps, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.g0[p], a.n_ticks[p]);
+      const StepOut o = agent_period<TICK, XMODE>(cfgk, tc, a.mdp, a.mdp_run, e, qx, a.qa, a.qb, a.mode, a.eps_thr, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.mgr0[p], a.sched[p]);
+      DQL_SECTION("accumulate");
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
         if (o.cell_y >= 0) { atomicAdd(&sT[o.cell_y], (unsigned long long)o.target_y_fx); atomicAdd(&sM[o.cell_y], 1u); }
@@ -384,6 +414,7 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
       for (int k = 0; k <= DQL_TERMINAL_TIMEOUT; ++k) code_w[k] += (unsigned)__popcll(__ballot(done_code == k));
     }
   }
+  DQL_SECTION("store");
   if (i < a.n) {
     store_env(e, a.sr, a.si, a.n, i, XMODE == X_ONLY ? x_only(a.c) : a.c);  // the atomics went out first: their round trip hides behind the state stores
     DQL_MARK_T(e, 6);
@@ -558,6 +589,74 @@ __global__ void k_plant_run(SimK<T> c, long long n_series, long long n_ticks, co
     for (int k = 0; k < 3; ++k) { o[k] = e.p[k]; o[3 + k] = e.v[k]; o[10 + k] = e.w[k]; }
     for (int k = 0; k < 4; ++k) { o[6 + k] = e.q[k]; o[13 + k] = e.om[k]; }
     o[17] = e.mp_x; o[18] = e.mp_y; o[19] = (e.flags & FL_CONTACT) ? 1.0 : 0.0;
+  }
+}
+// ---- the control-side functions of the tick replayed alone (dql_butterworth_run, dql_kalman_run, dql_pid_run, dql_attitude_run,
+// dql_platform_run): the SAME device functions the fused step calls, one lane, so that each can be held against the reference's own
+// outputs (golden vectors G8, G9, G11) in float64 AND in the float32 forms every throughput figure runs on ----
+template <typename T> struct FiltK { T dt, bw_k1, bw_k2, bw_inv, bw_b2, bw_a2, bw_a3; };
+template <typename T> static FiltK<T> make_filtk(double bc) {  // pkg/filters.py:94-106, as make_simk has it
+  const double denom = 1 + bc * bc + 1.414 * bc;
+  FiltK<T> d;
+  d.dt = T(0); d.bw_inv = (T)(1.0 / denom); d.bw_k1 = (T)(bc * bc - 1.414 * bc + 1); d.bw_k2 = (T)(-2 * bc * bc + 2);
+  d.bw_b2 = (T)(2.0 / denom); d.bw_a2 = (T)((-2 * bc * bc + 2) / denom); d.bw_a3 = (T)((bc * bc - 1.414 * bc + 1) / denom);
+  return d;
+}
+template <typename T> __global__ void k_butterworth_run(FiltK<T> c, const double* x, long long n, double* y) {  // pkg/filters.py:98-109 from zero histories
+  if (blockIdx.x || threadIdx.x) return;
+  T x1 = T(0), x2 = T(0), y1 = T(0), y2 = T(0), y3 = T(0);
+  for (long long i = 0; i < n; ++i) y[i] = (double)butterworth(c, (T)x[i], x1, x2, y1, y2, y3);
+}
+// KalmanFilter3D.filter over a velocity series (pkg/filters.py:53-80): z = dv / dt with the timestamps 0.01 i, dt <= 0 -> 0.01 (dt_le0[i] forces that branch)
+template <typename T> __global__ void k_kalman_run(T Q, T Rm, const double* vel, const uint8_t* dt_le0, long long n, double* acc) {
+  if (blockIdx.x || threadIdx.x) return;
+  T x[3] = {T(0), T(0), T(0)}, P[3] = {T(1), T(1), T(1)};
+  for (long long i = 1; i < n; ++i) {
+    T dt_ = dt_le0[i] ? T(0.0) : (T)(0.01 * (double)i) - (T)(0.01 * (double)(i - 1));
+    if (dt_ <= T(0.0)) dt_ = T(0.01);
+    for (int k = 0; k < 3; ++k) acc[(i - 1) * 3 + k] = (double)kalman1d(x[k], P[k], Q, Rm, ((T)vel[i * 3 + k] - (T)vel[(i - 1) * 3 + k]) / dt_);
+  }
+}
+// PID.output replay (pkg/pid.py:62-104, Kd = 0): the plant state is sampled every 5th tick, tick times are 0.002 (i + 1)
+template <typename T> struct PidP { T kp, ki, lo, hi, wind, sp; };
+template <typename T> __global__ void k_pid_run(FiltK<T> c, PidP<T> p, const double* state, long long n, double* effort, double* integral) {
+  if (blockIdx.x || threadIdx.x) return;
+  T integ = T(0), x1 = T(0), x2 = T(0), y1 = T(0), y2 = T(0), y3 = T(0), st = T(0), prev_t = T(0);
+  for (long long i = 0; i < n; ++i) {
+    const T t = (T)(0.002 * (double)(i + 1));
+    if (i % 5 == 0) st = (T)state[i];
+    c.dt = t - prev_t;
+    effort[i] = (double)pid_output(c, p.kp, p.ki, p.lo, p.hi, p.wind, p.sp, st, integ, x1, x2, y1, y2, y3);
+    integral[i] = (double)integ;
+    prev_t = t;
+  }
+}
+// AttitudeController.compute_rotor_velocities (pkg/attitude_controller.py:107-156) for n samples: quaternion (x, y, z, w) as ROS has it, body rates,
+// cmd = roll, pitch, yaw rate, thrust -> commanded rotor speeds.  xonly: the x-axis closed form the x-axis kernels compile in (roll command exactly 0)
+template <typename T> __global__ void k_attitude_run(SimK<T> s, const double* quat_xyzw, const double* omega, const double* cmd, long long n, int xonly, double* rotor) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T q[4] = {(T)quat_xyzw[i * 4 + 3], (T)quat_xyzw[i * 4 + 0], (T)quat_xyzw[i * 4 + 1], (T)quat_xyzw[i * 4 + 2]};
+  const T w[3] = {(T)omega[i * 3], (T)omega[i * 3 + 1], (T)omega[i * 3 + 2]};
+  T R[9], cy, sy, ct, rn, B[9], out[4];
+  quat_to_R(q, R); yaw_cs(R, cy, sy, ct, rn);
+  make_B((T)cmd[i * 4 + 1], (T)cmd[i * 4 + 0], B);
+  attitude(s, R, w, B, cy, sy, ct, rn, (T)cmd[i * 4 + 2], (T)cmd[i * 4 + 3], out, xonly != 0);
+  for (int k = 0; k < 4; ++k) rotor[i * 4 + k] = (double)out[k];
+}
+// MovingPlatform.compute_trajectory (pkg/moving_platform.py:87-127) from phase 0: x, y, u, v at successive 100 Hz ticks.  carry > 0: sine and cosine
+// are evaluated at every carry-th tick only and rotated through the constant phase step in between — what the fused float32 step does inside an
+// agent period (platform_update with a PlatRec; four or five manager ticks per period)
+template <typename T> __global__ void k_platform_run(SimK<T> s, long long n, int carry, double* out) {
+  if (blockIdx.x || threadIdx.x) return;
+  Env<T> e;
+  memset(&e, 0, sizeof(e));
+  e.mp_r = s.mp_r; e.mp_w = s.mp_w;
+  PlatRec<T> rec = PlatRec<T>{};
+  for (long long i = 0; i < n; ++i) {
+    if (carry > 0) platform_update(s, e, &rec, i % carry == 0);
+    else platform_update(s, e);
+    out[i * 4] = (double)e.mp_x; out[i * 4 + 1] = (double)e.mp_y; out[i * 4 + 2] = (double)e.mp_u; out[i * 4 + 3] = (double)e.mp_v;
   }
 }
 // exhaustive self-test of sqrt_pos (dql_selftest_sqrt): inputs with bit patterns lo .. hi against (float)sqrt((double)x)
@@ -751,6 +850,7 @@ struct dql_ctx {
   bool pending = false;          // acc[(launch_index + 1) & 1] holds the last launch's accumulators, not yet folded into the master tables
   uint8_t* d_actions = nullptr;
   void* mdpk = nullptr;  // MdpK<T> in device memory
+  KalFix kal_fix{0.0, 0.0, false};  // fixed point of the Kalman covariance in this context's dtype (create_impl)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per-launch event pairs while the kernel timer is armed
@@ -760,7 +860,7 @@ struct dql_ctx {
   bool windowed = false;
   int block = 0;  // 0 = auto
   int tick = 0;   // 0 = auto, 1 plain loop, 2 VGPR constants + grouped loop, 3 packed float32 tick, 4 literal constants (reference vehicle)
-  bool lit_ok = false;  // float32 and the tick constants are bit-identical to dql_refk.inc
+  bool lit_ok = false;  // float32 and the tick AND MDP constants are bit-identical to dql_refk.inc
   unsigned long long* elog = nullptr;  // episode log: [elog_cap][2][n_waves] ballots of finished / goal-reached episodes
   int elog_cap = 0, elog_n = 0;
   uint8_t* h_actions = nullptr; void* h_actions_dev = nullptr;  // pinned, device-visible staging of dql_step's host actions
@@ -800,6 +900,8 @@ static int check_config(const dql_config* c) {
   if (c->dtype != DQL_F32 && c->dtype != DQL_F64) return fail(DQL_EINVAL, "dtype must be DQL_F32 or DQL_F64");
   if (c->pid_vz[2] != 0.0 || c->pid_yaw[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported by the fused kernel (reference launch files use Kd = 0)");
   if (c->manager_div < 1 || c->dt <= 0 || c->f_ag <= 0) return fail(DQL_EINVAL, "dt, f_ag, manager_div must be positive");
+  // the per-period tick schedule travels packed in one kernel-argument word (StepArgs::sched): 8 bits each for the period's physics ticks and the manager divider
+  if (c->manager_div > 255 || !(1.0 / (c->f_ag * c->dt) + 1.0 < 256.0)) return fail(DQL_EINVAL, "an agent period must hold fewer than 255 physics ticks (1 / (f_ag dt)) and manager_div must be <= 255");
   if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
   if (c->init_uniform < 0 || c->init_uniform > 2) return fail(DQL_EINVAL, "init_uniform must be 0 (normal at level 0, else uniform), 1 (uniform) or 2 (SimulationLandingEnv placement)");
   // step_count and curriculum_check are packed into 16 bits each (store_env): an episode must time out before they wrap
@@ -828,13 +930,21 @@ template <typename T> static int launch_init(dql_ctx* x) {
 }
 
 static FoldK make_foldk(const dql_ctx* x, long long n_launch = 1) { return FoldK{x->alpha_tab, x->n_tab, x->cfg.alpha_min, x->cfg.fold_per_step, n_launch}; }
+// number of k in [0, 2^24) with k 2^-24 < eps (the values u24() takes): eps 2^24 is exact in double, so this is the SAME predicate as the
+// reference-shaped `uniform < eps` (pkg/double_q_learning.py:113), evaluated among integers
+static unsigned int eps_threshold(double eps) {
+  if (!(eps > 0.0)) return 0u;
+  const double t = std::ceil(eps * 16777216.0);
+  return t >= 16777216.0 ? 16777216u : (unsigned int)t;
+}
 static long long ticks_before(const dql_ctx* x, long long j) { return (long long)std::floor((double)j * (1.0 / (x->cfg.f_ag * x->cfg.dt))); }
 
 template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, double eps, int envs_per_block, int n_periods) {
   const long long j = x->step_index, l = x->launch_index;
   StepArgs<T> a;
-  a.c = make_simk<T>(x->cfg);
+  a.c = make_simk<T>(x->cfg, &x->kal_fix);
   a.mdp = (const MdpK<T> DQL_CONST_AS*)x->mdpk;
+  a.mdp_run = MdpRun<T>{x->cfg.gamma, (T)(x->cfg.t_max * x->cfg.f_ag), x->cfg.goal_logic};
   a.sr = (Quad<T>*)x->sr; a.si = x->si;
   a.qa = x->tb[l & 1]; a.qb = x->tbb[l & 1]; a.acc_cur = (unsigned long long*)x->acc[l & 1];
   a.qa_m = x->qa; a.qb_m = x->qb; a.cnt_m = x->count; a.qa_pub = x->tb[(l + 1) & 1]; a.qb_pub = x->tbb[(l + 1) & 1];
@@ -842,8 +952,16 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   a.fold = make_foldk(x, x->pending_periods); a.stats = x->stats; a.actions = x->ext_actions ? x->ext_actions : x->d_actions;
   a.elog = x->elog ? x->elog + (size_t)x->elog_n * 2 * (size_t)((x->n + 63) >> 6) : nullptr;
   a.n = x->n; a.env_id_offset = x->env_id_offset; a.step_index = j;
-  for (int p = 0; p < DQL_MAX_PERIODS; ++p) { a.g0[p] = ticks_before(x, j + p); a.n_ticks[p] = (int)(ticks_before(x, j + p + 1) - a.g0[p]); }
-  a.seed = x->seed; a.eps = eps; a.mode = mode; a.n_periods = n_periods;
+  for (int p = 0; p < DQL_MAX_PERIODS; ++p) {
+    const long long g0 = ticks_before(x, j + p);
+    const int n_ticks = (int)(ticks_before(x, j + p + 1) - g0), div = x->cfg.manager_div;
+    const int phase = (int)(g0 % div);                                   // physics ticks since the last 100 Hz manager tick
+    a.mgr0[p] = g0 / div + (phase ? 1 : 0);                              // index of the next manager tick
+    const int first_mgr = phase ? div - phase : 0;
+    const int last_mgr = first_mgr < n_ticks ? (n_ticks - 1 - first_mgr) / div : 0;
+    a.sched[p] = n_ticks | (phase << 8) | (last_mgr << 16);              // check_config: n_ticks, manager_div <= 255
+  }
+  a.seed = x->seed; a.eps_thr = eps_threshold(eps); a.pad_ = 0; a.mode = mode; a.n_periods = n_periods;
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
   return a;
 }
@@ -1021,7 +1139,9 @@ static int create_impl(dql_ctx* x, const dql_config* cfg) {
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } while (0)
   HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&x->ev0)); HIP_TRY(hipEventCreate(&x->ev1));
-  x->lit_ok = cfg->dtype == DQL_F32 && refk_matches(make_simk<float>(*cfg));
+  if (cfg->dtype == DQL_F32) { const SimK<float> k = make_simk<float>(*cfg); x->kal_fix = KalFix{(double)k.kal_pss, (double)k.kal_kss, true}; }
+  else { const SimK<double> k = make_simk<double>(*cfg); x->kal_fix = KalFix{k.kal_pss, k.kal_kss, true}; }
+  x->lit_ok = cfg->dtype == DQL_F32 && refk_matches(make_simk<float>(*cfg, &x->kal_fix)) && refm_matches(make_mdpk<float>(*cfg));
   ALLOC(x->sr, (size_t)NQ_REAL * (size_t)x->n * 4 * x->real_size);
   ALLOC(x->si, (size_t)x->n * sizeof(int4));
   ALLOC(x->qa, DQL_N_CELLS * sizeof(double)); ALLOC(x->qb, DQL_N_CELLS * sizeof(double)); ALLOC(x->count, DQL_N_CELLS * sizeof(double));
@@ -1602,7 +1722,7 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   }
   if (!strcmp(name, "tick")) {
     if (value < 0 || value > 4) return fail(DQL_EINVAL, "tick must be 0 (auto), 1 (plain), 2 (VGPR constants), 3 (packed float32) or 4 (literal constants)");
-    if (value == 4 && !x->lit_ok) return fail(DQL_EINVAL, "tick 4 serves float32 contexts whose vehicle / controller constants are the reference's (tools/gen_refk.py); this context's differ");
+    if (value == 4 && !x->lit_ok) return fail(DQL_EINVAL, "tick 4 serves float32 contexts whose vehicle / controller / MDP constants are the reference's (tools/gen_refk.py); this context's differ");
     x->tick = value;
     return DQL_OK;
   }
@@ -1769,6 +1889,92 @@ int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n
   else hipLaunchKernelGGL(k_plant_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(*cfg), (long long)n_series, (long long)n_ticks, (const double*)a.p, (const double*)b.p, (double*)o.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, o.p, cells * 20 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_butterworth_run(const dql_config* cfg, int device, const double* x, int64_t n, double* y_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 0 && (!x || !y_out))) return fail(DQL_EINVAL, "null array");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, o;
+  UP(a, x, (size_t)n * sizeof(double));
+  if (o.alloc((size_t)n * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_butterworth_run<float>, dim3(1), dim3(64), 0, 0, make_filtk<float>(cfg->bw_c), (const double*)a.p, (long long)n, (double*)o.p);
+  else hipLaunchKernelGGL(k_butterworth_run<double>, dim3(1), dim3(64), 0, 0, make_filtk<double>(cfg->bw_c), (const double*)a.p, (long long)n, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(y_out, o.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_kalman_run(const dql_config* cfg, int device, const double* vel, const uint8_t* dt_le0, int64_t n, double* acc_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 1 && (!vel || !dt_le0 || !acc_out))) return fail(DQL_EINVAL, "null array");
+  if (n <= 1) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, b, o;
+  UP(a, vel, (size_t)n * 3 * sizeof(double)); UP(b, dt_le0, (size_t)n);
+  if (o.alloc((size_t)(n - 1) * 3 * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const double r = cfg->noise_vel_sd * cfg->noise_vel_sd;  // pkg/filters.py:49
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_kalman_run<float>, dim3(1), dim3(64), 0, 0, (float)cfg->kalman_q, (float)r, (const double*)a.p, (const uint8_t*)b.p, (long long)n, (double*)o.p);
+  else hipLaunchKernelGGL(k_kalman_run<double>, dim3(1), dim3(64), 0, 0, (double)cfg->kalman_q, r, (const double*)a.p, (const uint8_t*)b.p, (long long)n, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(acc_out, o.p, (size_t)(n - 1) * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_pid_run(const dql_config* cfg, int device, const double* params, const double* state, int64_t n, double* effort_out, double* integral_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (!params || n < 0 || (n > 0 && (!state || !effort_out || !integral_out))) return fail(DQL_EINVAL, "null array");
+  if (params[2] != 0.0) return fail(DQL_EINVAL, "Kd != 0 is not supported (the reference launches both controllers with Kd = 0, launch/drone.launch:37,51)");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, o, g;
+  UP(a, state, (size_t)n * sizeof(double));
+  if (o.alloc((size_t)n * sizeof(double)) || g.alloc((size_t)n * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  if (cfg->dtype == DQL_F32) {
+    const PidP<float> p{(float)params[0], (float)params[1], (float)params[3], (float)params[4], (float)params[5], (float)params[6]};
+    hipLaunchKernelGGL(k_pid_run<float>, dim3(1), dim3(64), 0, 0, make_filtk<float>(cfg->bw_c), p, (const double*)a.p, (long long)n, (double*)o.p, (double*)g.p);
+  } else {
+    const PidP<double> p{params[0], params[1], params[3], params[4], params[5], params[6]};
+    hipLaunchKernelGGL(k_pid_run<double>, dim3(1), dim3(64), 0, 0, make_filtk<double>(cfg->bw_c), p, (const double*)a.p, (long long)n, (double*)o.p, (double*)g.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(effort_out, o.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(integral_out, g.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_attitude_run(const dql_config* cfg, int device, const double* quat_xyzw, const double* omega, const double* cmd, int64_t n, int32_t xonly, double* rotor_out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || (n > 0 && (!quat_xyzw || !omega || !cmd || !rotor_out))) return fail(DQL_EINVAL, "null array");
+  if (xonly && cfg->dtype != DQL_F32) return fail(DQL_EINVAL, "the x-axis closed form of the attitude law exists in float32 only");
+  if (xonly) for (int64_t i = 0; i < n; ++i) if (cmd[i * 4] != 0.0) return fail(DQL_EINVAL, "the x-axis closed form needs a roll command of exactly 0");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf a, b, c, o;
+  UP(a, quat_xyzw, (size_t)n * 4 * sizeof(double)); UP(b, omega, (size_t)n * 3 * sizeof(double)); UP(c, cmd, (size_t)n * 4 * sizeof(double));
+  if (o.alloc((size_t)n * 4 * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_attitude_run<float>, dim3(grid), dim3(64), 0, 0, make_simk<float>(*cfg), (const double*)a.p, (const double*)b.p, (const double*)c.p, (long long)n, (int)xonly, (double*)o.p);
+  else hipLaunchKernelGGL(k_attitude_run<double>, dim3(grid), dim3(64), 0, 0, make_simk<double>(*cfg), (const double*)a.p, (const double*)b.p, (const double*)c.p, (long long)n, (int)xonly, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(rotor_out, o.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  return DQL_OK;
+}
+
+int dql_platform_run(const dql_config* cfg, int device, int64_t n, int32_t carry, double* out) {
+  int rc = check_config(cfg); if (rc) return rc;
+  if (n < 0 || carry < 0 || (n > 0 && !out)) return fail(DQL_EINVAL, "bad argument");
+  if (carry && cfg->dtype != DQL_F32) return fail(DQL_EINVAL, "the carried sine / cosine exists in the float32 step only");
+  if (n == 0) return DQL_OK;
+  OP_PROLOGUE(device)
+  DevBuf o;
+  if (o.alloc((size_t)n * 4 * sizeof(double))) return fail(DQL_ENOMEM, "hipMalloc failed");
+  if (cfg->dtype == DQL_F32) hipLaunchKernelGGL(k_platform_run<float>, dim3(1), dim3(64), 0, 0, make_simk<float>(*cfg), (long long)n, (int)carry, (double*)o.p);
+  else hipLaunchKernelGGL(k_platform_run<double>, dim3(1), dim3(64), 0, 0, make_simk<double>(*cfg), (long long)n, (int)carry, (double*)o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, o.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
   return DQL_OK;
 }
 

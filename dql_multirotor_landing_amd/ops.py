@@ -72,6 +72,61 @@ def plant_run(cfg: DqlConfig, init, rotor_cmd, device: int = 0) -> np.ndarray:
     return out
 
 
+def butterworth_run(cfg: DqlConfig, x, device: int = 0) -> np.ndarray:
+    """ButterworthFilter.update (pkg/filters.py:98-109) over a series from zero histories, in cfg.dtype arithmetic."""
+    x = _f64(x)
+    if x.ndim != 1:
+        raise ValueError("x must be 1-D")
+    y = np.zeros_like(x)
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_butterworth_run(C.byref(c), device, _p(x), len(x), _p(y)))
+    return y
+
+
+def kalman_run(cfg: DqlConfig, vel, dt_le0, device: int = 0) -> np.ndarray:
+    """KalmanFilter3D.filter (pkg/filters.py:53-80) over vel [n][3] sampled at 100 Hz -> acceleration estimates [n - 1][3]
+    (Q = cfg.kalman_q, R = cfg.noise_vel_sd ** 2; dt_le0[i] forces the reference's dt <= 0 branch)."""
+    vel = _f64(vel); flags = np.ascontiguousarray(dt_le0, dtype=np.uint8)
+    if vel.ndim != 2 or vel.shape[1] != 3 or flags.shape != (len(vel),):
+        raise ValueError("vel must be [n][3], dt_le0 [n]")
+    acc = np.zeros((max(len(vel) - 1, 0), 3))
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_kalman_run(C.byref(c), device, _p(vel), _p(flags), len(vel), _p(acc)))
+    return acc
+
+
+def pid_run(cfg: DqlConfig, params, state, device: int = 0):
+    """PID.output (pkg/pid.py:62-104) over 500 Hz ticks; params = Kp Ki Kd lower upper windup setpoint (Kd = 0) -> (effort, integral)."""
+    params = _f64(params); state = _f64(state)
+    if params.shape != (7,) or state.ndim != 1:
+        raise ValueError("params must have 7 entries, state must be 1-D")
+    eff = np.zeros(len(state)); integ = np.zeros(len(state))
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_pid_run(C.byref(c), device, _p(params), _p(state), len(state), _p(eff), _p(integ)))
+    return eff, integ
+
+
+def attitude_run(cfg: DqlConfig, quat_xyzw, omega, cmd, xonly: int = 0, device: int = 0) -> np.ndarray:
+    """AttitudeController.compute_rotor_velocities (pkg/attitude_controller.py:107-156): quaternions (x, y, z, w), body rates,
+    cmd = roll, pitch, yaw rate, thrust -> commanded rotor speeds [n][4]."""
+    q, w, u = map(_f64, (quat_xyzw, omega, cmd))
+    n = len(q)
+    if q.shape != (n, 4) or w.shape != (n, 3) or u.shape != (n, 4):
+        raise ValueError("quat_xyzw must be [n][4], omega [n][3], cmd [n][4]")
+    rot = np.zeros((n, 4))
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_attitude_run(C.byref(c), device, _p(q), _p(w), _p(u), n, int(xonly), _p(rot)))
+    return rot
+
+
+def platform_run(cfg: DqlConfig, n: int, carry: int = 0, device: int = 0) -> np.ndarray:
+    """MovingPlatform.compute_trajectory (pkg/moving_platform.py:87-127) from phase 0 -> [n][4] = x, y, u, v per 100 Hz tick."""
+    out = np.zeros((int(n), 4))
+    c = cfg.to_c()
+    _lib.check(_lib.load().dql_platform_run(C.byref(c), device, int(n), int(carry), _p(out)))
+    return out
+
+
 def selftest_sqrt(lo: float = 1e-30, hi: float = 3.4028234663852886e38, device: int = 0) -> int:
     """number of float32 inputs in [lo, hi] for which the float32 tick's square root is not the correctly rounded one (must be 0)"""
     lo_b = int(np.float32(lo).view(np.uint32)); hi_b = int(np.float32(hi).view(np.uint32))

@@ -76,6 +76,7 @@ from .dist import LocalWindowReducer, ShardedRunner, shard_range
 from .double_q_learning import ASSETS_PATH, DoubleQLearningAgent, StateAction
 from .engine import Engine
 from .promotion import EpisodeOrder, PromotionWindow
+from .state_layout import STATE_LAYOUT_VERSION, convert_env_state
 
 _TS = r"%d-%m-%Y %H:%M:%S"
 _TERMINAL = CHECK_NAMES[:7]
@@ -234,21 +235,28 @@ class Trainer:
             reals, ints = eng.get_fields()
             f = self._env_state_file(self._rank)
             tmp = f.with_name(f".{f.name}.{os.getpid()}.tmp.npz")
+            # dtype + state_layout: the two PIDs' filter fields mean different things per dtype (state_layout.py); a shard is only flown by a
+            # context it was written for, or after the one mapping that exists (float64 histories -> float32 transposed states)
             np.savez(tmp, reals=reals.astype(np.float32 if self._dtype == F32 else np.float64), ints=ints, step_index=np.int64(eng.step_index()),
-                     **{f"tag_{k}": np.int64(v) for k, v in tag.items()})
+                     dtype=np.int64(self._dtype), state_layout=np.int64(STATE_LAYOUT_VERSION), **{f"tag_{k}": np.int64(v) for k, v in tag.items()})
             os.replace(tmp, f)
         if self._comm is not None and self._world > 1:
             self._comm.barrier()  # every rank's shard of this checkpoint is on disk before rank 0 publishes it
         if self._rank != 0:  # table replicas are identical after a sync: rank 0 writes
             return
         self._save_path.mkdir(parents=True, exist_ok=True)
+        # the three .npy files keep the reference's layout, so the checkpoint they belong to is named NEXT to them, and the name brackets the
+        # writes: "in_progress" before the first table, the plain tag after the last.  A run killed between two of the three table files leaves
+        # the in-progress tag (load() warns: the tables may mix two checkpoints); killed between the tables and trainer.json it leaves newer
+        # tables under the older progress counters, and load() says so
+        def write_tag(t):
+            tmp = self._save_path / f".tables.tag.json.{os.getpid()}.tmp"
+            tmp.write_text(json.dumps(t))
+            os.replace(tmp, self._save_path / "tables.tag.json")
+        write_tag(dict(tag, in_progress=1))
         self._double_q_learning_agent.save(self._save_path)
         self._double_q_learning_agent.save(self._save_path / "..")
-        # the three .npy files keep the reference's layout, so the checkpoint they belong to is named NEXT to them: a run killed between the
-        # tables and trainer.json leaves newer tables under the older progress counters, and load() says so
-        tmp = self._save_path / f".tables.tag.json.{os.getpid()}.tmp"
-        tmp.write_text(json.dumps(tag))
-        os.replace(tmp, self._save_path / "tables.tag.json")
+        write_tag(tag)
         st = self._state_dict()
         if st["progress"] is not None:
             st["progress"] = dict(st["progress"], tag=tag)
@@ -279,7 +287,10 @@ class Trainer:
         except (OSError, ValueError):
             tables_tag = None
         want_tag = (st.get("progress") or {}).get("tag")
-        if tables_tag is not None and want_tag is not None and tables_tag != want_tag:
+        if tables_tag is not None and tables_tag.pop("in_progress", 0):
+            warnings.warn(f"the tables in {run.name} were being written (checkpoint {tables_tag}) when the run stopped: the three .npy files may belong to two "
+                          "different checkpoints — resuming with them as they are", RuntimeWarning)
+        elif tables_tag is not None and want_tag is not None and tables_tag != want_tag:
             warnings.warn(f"the tables in {run.name} belong to checkpoint {tables_tag}, trainer.json to {want_tag}: the run was stopped between the two "
                           "writes — resuming with the newer tables under the older progress and episode counters", RuntimeWarning)
         build = dict(st.get("build", {"n_envs": st.get("n_envs", 4096), "mode": st.get("mode", "reference")}))
@@ -391,6 +402,16 @@ class Trainer:
             warnings.warn(f"{f.name} belongs to checkpoint {have or 'without a tag'}, trainer.json to {want}: resuming level {progress.get('level')} "
                           "from its tables without the saved simulator state", RuntimeWarning)
             return None
+        # which dtype's layout the shard holds (files written before round 5 carry no field: the array's own dtype, layout 1 = histories everywhere)
+        src_dtype = int(z["dtype"]) if "dtype" in z.files else (F32 if z["reals"].dtype == np.float32 else 1)
+        src_layout = int(z["state_layout"]) if "state_layout" in z.files else 1
+        reals = convert_env_state(z["reals"].astype(np.float64), eng.field_names(), src_dtype, self._dtype, src_layout, bw_c=self._env_kw.get("bw_c", 1.0))
+        if reals is None:
+            warnings.warn(f"{f.name} holds the simulator state of a {'float32' if src_dtype == F32 else 'float64'} context (layout {src_layout}) and this run is "
+                          f"{'float32' if self._dtype == F32 else 'float64'}: the float32 filter states do not determine the float64 histories — resuming level "
+                          f"{progress.get('level')} from its tables without the saved simulator state", RuntimeWarning)
+            return None
+        z = {"reals": reals, "ints": z["ints"], "step_index": z["step_index"]}
         if z["ints"].shape[1] != eng.n:  # raised by _restore_env_state on EVERY rank, after the vote (a lone raise here would leave the others in the collective)
             self._env_state_error = f"{f} holds {z['ints'].shape[1]} envs, this rank's shard has {eng.n}"
             return None
@@ -411,7 +432,7 @@ class Trainer:
             raise ValueError(self._env_state_error or "another rank's env-state shard holds a different env count than its engine (see that rank's message)")
         if not ok:
             return False
-        eng.set_fields(z["reals"].astype(np.float64), z["ints"])
+        eng.set_fields(np.asarray(z["reals"], dtype=np.float64), z["ints"])
         eng.set_step_index(int(z["step_index"]))
         return True
 

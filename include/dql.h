@@ -356,6 +356,26 @@ int dql_manager_run(const dql_config* cfg, int device, int64_t n_series, int64_t
  * quaternion(4), body rates(3), rotor speeds(4), platform x y, contact latch (0 / 1) AFTER each tick.  Exists so that tests can hold
  * the plant against closed forms (tests/test_plant_closed_forms.py); Gazebo itself cannot run here (parity vs Gazebo: unpinned). */
 int dql_plant_run(const dql_config* cfg, int device, int64_t n_series, int64_t n_ticks, const double* init, const double* rotor_cmd, double* out);
+/* ---- the control-side functions of the 500 Hz / 100 Hz ticks replayed ALONE, one call per reference class method, with the device functions
+ * the fused step kernel runs (float64: the reference's expressions operation by operation; float32: the forms every throughput figure runs on).
+ * They exist so that each function can be held against the reference's own outputs (tests/golden G8, G9, G11) in BOTH dtypes ---- */
+/* ButterworthFilter.update (pkg/filters.py:98-109) over x[n] from zero histories, c = cfg->bw_c */
+int dql_butterworth_run(const dql_config* cfg, int device, const double* x, int64_t n, double* y_out);
+/* KalmanFilter3D.filter (pkg/filters.py:53-80) over a velocity series vel[n][3] sampled at t = 0.01 i: z = dv / dt, dt <= 0 -> 0.01 (dt_le0[i] != 0
+ * forces that branch), Q = cfg->kalman_q, R = cfg->noise_vel_sd^2 -> acc_out[n - 1][3] */
+int dql_kalman_run(const dql_config* cfg, int device, const double* vel, const uint8_t* dt_le0, int64_t n, double* acc_out);
+/* PID.output (pkg/pid.py:62-104) replayed over n 500 Hz ticks at t = 0.002 (i + 1); params[7] = Kp Ki Kd lower upper windup setpoint (Kd must be 0:
+ * launch/drone.launch:37,51), state[n] sampled every 5th tick as the 100 Hz manager publishes it -> control effort and integral per tick */
+int dql_pid_run(const dql_config* cfg, int device, const double* params, const double* state, int64_t n, double* effort_out, double* integral_out);
+/* AttitudeController.compute_rotor_velocities (pkg/attitude_controller.py:107-156) for n samples: quat_xyzw[n][4] (ROS order), omega[n][3] body rates,
+ * cmd[n][4] = roll, pitch, yaw rate, thrust -> rotor_out[n][4] commanded rotor speeds (rad/s).  xonly = 1 (float32 only, every roll command
+ * exactly 0): the closed form the x-axis kernels compile in */
+int dql_attitude_run(const dql_config* cfg, int device, const double* quat_xyzw, const double* omega, const double* cmd, int64_t n, int32_t xonly,
+                     double* rotor_out);
+/* MovingPlatform.compute_trajectory (pkg/moving_platform.py:87-127) from phase 0 -> out[n][4] = x, y, u, v at successive 100 Hz ticks.  carry > 0
+ * (float32 only): sine / cosine evaluated at every carry-th tick and rotated through the constant phase step in between, as the fused float32
+ * step carries them through the four or five manager ticks of an agent period */
+int dql_platform_run(const dql_config* cfg, int device, int64_t n, int32_t carry, double* out);
 /* Self-test of the float32 tick's square root (csrc/dql_device.hpp sqrt_pos: v_rsq_f32 + Goldschmidt step + residual correction): counts the
  * inputs with bit patterns lo_bits .. hi_bits whose result is NOT the correctly rounded sqrt.  The CPU oracle computes sqrtf(); parity is
  * bit for bit only while this count is 0 on the tick's domain [1e-30, FLT_MAX] — all 2.1e9 inputs take under a second. */

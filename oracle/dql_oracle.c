@@ -429,6 +429,9 @@ static REAL mdp_reward(const mdpc_t* m, REAL* shp, REAL* cum, int code, int cur_
 /* ------------------------------------------------------------------------------------------------
  * agent — pkg/double_q_learning.py (tables are float64 whatever REAL is)
  * ---------------------------------------------------------------------------------------------- */
+/* double -> int64 fixed point: round to nearest even, saturating at +-2^50 (csrc/dql_device.hpp fx_round: the kernel rounds with the 2^52 trick, which is
+ * llrint() on that range) */
+static inline long long fx_round(double x) { return llrint(fmin(fmax(x, -0x1p50), 0x1p50)); }
 static inline int argmax3(double a, double b, double c) { int k = 0; double v = a; if (b > v) { v = b; k = 1; } if (c > v) { k = 2; } return k; }
 /* :119-124 */
 static inline int agent_predict(const double* qa, const double* qb, int idx) {
@@ -960,8 +963,8 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   const int done = e->code <= DQL_TERMINAL_TIMEOUT;
   if (done) e->flags |= FL_DONE;
   st->decisions += 1;
-  st->reward_fx += llrint((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
-  if (two) st->reward_fx += llrint((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  st->reward_fx += fx_round((double)rew * (double)(1ll << DQL_TARGET_FRAC_BITS));
+  if (two) st->reward_fx += fx_round((double)rew_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
   if (done) { st->episodes += 1; st->by_code[e->code] += 1; }
   if (mode == 0) {
     /* TD target of _update_q_table (pkg/double_q_learning.py:136-145), accumulated in fixed point: accum = [4][N_CELLS] =
@@ -981,7 +984,7 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
       const double target = (double)rew + (gamma * boot) * (double)mask;
       const int cell = prev_idx * 3 + action;
       int64_t* acc = accum + (sel_b ? 2 * DQL_N_CELLS : 0);
-      acc[cell] += llrint(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      acc[cell] += fx_round(target * (double)(1ll << DQL_TARGET_FRAC_BITS));
       acc[DQL_N_CELLS + cell] += 1;
     }
     if (two) { /* the y transition updates the same shared tables (scripts/simulation.py:15-16 loads one table pair for both axes) */
@@ -995,7 +998,7 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
       const double target_y = (double)rew_y + (gamma * boot_y) * (double)mask_y;
       const int cell_y = prev_idy * 3 + action_y;
       int64_t* acc = accum + (sel_b ? 2 * DQL_N_CELLS : 0);
-      acc[cell_y] += llrint(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
+      acc[cell_y] += fx_round(target_y * (double)(1ll << DQL_TARGET_FRAC_BITS));
       acc[DQL_N_CELLS + cell_y] += 1;
     }
   }
@@ -1155,6 +1158,33 @@ EXPORT void ORC(attitude_run)(const dql_config* c, const double* quat_xyzw, cons
     attitude(&s, R, w, B, cy, sy, ct, rn, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M, 0);
     for (int k = 0; k < 3; ++k) moment[i * 3 + k] = M[k];
     for (int k = 0; k < 4; ++k) rotor[i * 4 + k] = out[k];
+  }
+}
+/* the same with the x-axis closed form of the float32 attitude law (roll command exactly 0; csrc/dql_device.hpp attitude(), xonly) */
+EXPORT void ORC(attitude_run_x)(const dql_config* c, const double* quat_xyzw, const double* omega, const double* cmd, int64_t n, int xonly, double* rotor) {
+  simc_t s; simc_init(&s, c);
+  for (int64_t i = 0; i < n; ++i) {
+    REAL q[4] = {(REAL)quat_xyzw[i * 4 + 3], (REAL)quat_xyzw[i * 4 + 0], (REAL)quat_xyzw[i * 4 + 1], (REAL)quat_xyzw[i * 4 + 2]};
+    REAL w[3] = {(REAL)omega[i * 3], (REAL)omega[i * 3 + 1], (REAL)omega[i * 3 + 2]};
+    REAL R[9], cy, sy, ct, rn, sp_, cp_, sr_, cr_, B[9], out[4], M[3];
+    quat_to_R(q, R); yaw_cs4(R, &cy, &sy, &ct, &rn);
+    det_sincos((REAL)cmd[i * 4 + 1], &sp_, &cp_); det_sincos((REAL)cmd[i * 4 + 0], &sr_, &cr_);
+    B[0] = cp_; B[1] = R_(0.0); B[2] = sp_; B[3] = sr_ * sp_; B[4] = cr_; B[5] = -(sr_ * cp_); B[6] = -(cr_ * sp_); B[7] = sr_; B[8] = cr_ * cp_;
+    attitude(&s, R, w, B, cy, sy, ct, rn, (REAL)cmd[i * 4 + 2], (REAL)cmd[i * 4 + 3], out, M, xonly);
+    for (int k = 0; k < 4; ++k) rotor[i * 4 + k] = out[k];
+  }
+}
+/* platform replay with the sine / cosine carried as the fused float32 step carries them inside an agent period: evaluated at every carry-th tick,
+ * rotated through the constant phase step in between (carry = 0: evaluated at every tick) */
+EXPORT void ORC(platform_run_carry)(const dql_config* c, int64_t n, int carry, double* out) {
+  simc_t s; simc_init(&s, c);
+  env_t e; memset(&e, 0, sizeof(e));
+  e.mp_r = s.mp_r; e.mp_w = s.mp_w;
+  platrec_t rec; memset(&rec, 0, sizeof(rec));
+  for (int64_t i = 0; i < n; ++i) {
+    if (carry > 0) platform_update(&s, &e, &rec, i % carry == 0);
+    else platform_update(&s, &e, NULL, 1);
+    out[i * 4] = e.mp_x; out[i * 4 + 1] = e.mp_y; out[i * 4 + 2] = e.mp_u; out[i * 4 + 3] = e.mp_v;
   }
 }
 /* platform trajectory replay from phase 0: out[n][4] = x, y, u, v at successive 100 Hz ticks */

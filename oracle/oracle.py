@@ -353,10 +353,23 @@ def attitude_run(cfg: DqlConfig, quat_xyzw, omega, cmd, dtype=1):
     return mom, rot
 
 
-def platform_run(cfg: DqlConfig, n, dtype=1):
+def attitude_rotors(cfg: DqlConfig, quat_xyzw, omega, cmd, xonly=0, dtype=None):
+    """rotor speeds only; xonly = 1: the x-axis closed form of the float32 attitude law (roll command 0)"""
+    quat_xyzw, omega, cmd = map(_f64, (quat_xyzw, omega, cmd))
+    n = len(quat_xyzw)
+    rot = np.zeros((n, 4))
+    c = cfg.to_c()
+    _run("attitude_run_x", cfg.dtype if dtype is None else dtype, C.byref(c), _p(quat_xyzw), _p(omega), _p(cmd), C.c_int64(n), C.c_int(int(xonly)), _p(rot))
+    return rot
+
+
+def platform_run(cfg: DqlConfig, n, dtype=1, carry=0):
     out = np.zeros((n, 4))
     c = cfg.to_c()
-    _run("platform_run", dtype, C.byref(c), C.c_int64(n), _p(out))
+    if carry:
+        _run("platform_run_carry", dtype, C.byref(c), C.c_int64(n), C.c_int(int(carry)), _p(out))
+    else:
+        _run("platform_run", dtype, C.byref(c), C.c_int64(n), _p(out))
     return out
 
 

@@ -116,6 +116,9 @@ def test_bootstrap_files_of_a_killed_job_are_polled_past(tmp_path, monkeypatch):
     h1 = comm._header(2)
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-7")
     assert comm._header(2) != h1 and len(h1) == 24               # without a job id: the run id and the parent's (pid, start time) make the nonce
+    h_run7 = comm._header(2)
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")         # attempt k + 1 of an elastic job (same agent, run id and port) is another job
+    assert comm._header(2) not in (h1, h_run7)
     monkeypatch.setattr(comm, "_parent_token", lambda: "1_1")
     assert comm._header(2) != h1
     monkeypatch.undo()

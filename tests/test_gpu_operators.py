@@ -259,3 +259,73 @@ def test_agent_mirror_argument_checks():
     _lib.check(upd(n, 5, 7)); _lib.check(lib.dql_agent_mirror_predict(h, p(qa), p(qb), p(cnt), n, 7, C.byref(act)))
     assert qa[5] == 0.5 * (1.0 + 0.99 * 0.0 * 0 - 0.0) and cnt[5] == 1.0 and act.value in (0, 1, 2)
     _lib.check(lib.dql_agent_destroy(h))
+
+
+# ---- round 5: every control-side function of the tick through the C ABI against the reference's own outputs, in BOTH dtypes ----
+# (the float32 legs are what ties the arithmetic every throughput figure runs on to reference-held data; bounds: tests/fixture_checks.py)
+@pytest.fixture(scope="module")
+def hip_be():
+    import fixture_checks as fc
+    return fc, fc.HipBackend(), fc.OracleBackend()
+
+
+@pytest.mark.parametrize("dtype", [F64, 0])
+def test_g8_filters_and_pid_on_hip(hip_be, dtype):
+    """pkg/filters.py:19-109 + pkg/pid.py:62-104 (G8): dql_butterworth_run / dql_kalman_run / dql_pid_run"""
+    fc, hip, _ = hip_be
+    fc.check_g8_butterworth(hip, dtype)
+    fc.check_g8_kalman(hip, dtype)
+    fc.check_g8_pid(hip, dtype)
+
+
+@pytest.mark.parametrize("dtype", [F64, 0])
+def test_g9_rotor_speeds_on_hip(hip_be, dtype):
+    """pkg/attitude_controller.py:107-156 (G9) down to the rotor command, v_rsq + Goldschmidt root and med3 clamp included: dql_attitude_run"""
+    fc, hip, _ = hip_be
+    fc.check_g9_rotor_speeds(hip, dtype)
+    if dtype == 0:
+        fc.check_g9_xonly_form(hip)
+
+
+@pytest.mark.parametrize("dtype,carry", [(F64, 0), (0, 0), (0, 4), (0, 5)])
+def test_g11_platform_on_hip(hip_be, dtype, carry):
+    """pkg/moving_platform.py:87-127 (G11), incl. the rotation-carried sine / cosine of the float32 step: dql_platform_run"""
+    fc, hip, _ = hip_be
+    fc.check_g11_platform(hip, dtype, carry)
+
+
+def test_g12_manager_tick_f32_on_hip(hip_be):
+    """scripts/manager_node.py:192-214 + pkg/observation_utils.py:99-158 (G12) in float32 — Kalman fixed-point shortcut (the covariance
+    reaches its fixed point ~100 ticks into the 300-tick series) and noise draws included: dql_manager_run"""
+    fc, hip, _ = hip_be
+    fc.check_g12_manager_f32(hip)
+
+
+@pytest.mark.parametrize("dtype", [F64, 0])
+def test_tick_operators_equal_the_oracle_bit_for_bit(hip_be, golden_dir, dtype):
+    """same dtype, same operation sequence: HIP == oracle exactly, for every replay operator (what makes the oracle's fixture pins the kernel's)"""
+    fc, hip, orc = hip_be
+    g8 = np.load(golden_dir / "g8_filters.npz"); g9 = np.load(golden_dir / "g9_attitude.npz")
+    cfg = DqlConfig(dtype=dtype)
+    np.testing.assert_array_equal(hip.butterworth_run(cfg, g8["bw_in"]), orc.butterworth_run(cfg, g8["bw_in"]))
+    flags = np.array([(i % 17 == 0) for i in range(120)], dtype=np.uint8)
+    ck = DqlConfig(dtype=dtype, noise_vel_sd=0.1)
+    np.testing.assert_array_equal(hip.kalman_run(ck, g8["kf_vel_r01"], flags), orc.kalman_run(ck, g8["kf_vel_r01"], flags))
+    for tag in ("vz", "yaw"):
+        a, b = hip.pid_run(cfg, g8[f"pid_{tag}_params"], g8[f"pid_{tag}_state"]), orc.pid_run(cfg, g8[f"pid_{tag}_params"], g8[f"pid_{tag}_state"])
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(hip.attitude_run(cfg, g9["quat_xyzw"], g9["omega"], g9["cmd"]), orc.attitude_run(cfg, g9["quat_xyzw"], g9["omega"], g9["cmd"]))
+    for carry in ((0, 4, 5) if dtype == 0 else (0,)):
+        np.testing.assert_array_equal(hip.platform_run(cfg, 1000, carry), orc.platform_run(cfg, 1000, carry))
+
+
+def test_tick_operator_argument_checks(ops):
+    with pytest.raises(ValueError):
+        ops.pid_run(DqlConfig(), [2.0, 0.5, 0.3, -4, 4, 1, 0.2], np.zeros(10))       # Kd != 0: launch/drone.launch:37,51 has none
+    with pytest.raises(ValueError):
+        ops.attitude_run(DqlConfig(dtype=F64), np.tile([0, 0, 0, 1.0], (2, 1)), np.zeros((2, 3)), np.zeros((2, 4)), xonly=1)
+    with pytest.raises(ValueError):
+        ops.attitude_run(DqlConfig(dtype=0), np.tile([0, 0, 0, 1.0], (2, 1)), np.zeros((2, 3)), np.array([[0.1, 0, 0, 7.0]] * 2), xonly=1)
+    with pytest.raises(ValueError):
+        ops.platform_run(DqlConfig(dtype=F64), 10, carry=5)
+    assert ops.platform_run(DqlConfig(), 0).shape == (0, 4)

@@ -147,6 +147,12 @@ def test_g9_attitude(golden_dir):
     tilt = np.degrees(np.arccos(np.sqrt(np.clip((1 - 2 * (y * y + z * z)) ** 2 + (2 * (x * y + w * z)) ** 2, 0, 1))))
     assert (tilt <= 45).sum() > 150 and tilt.max() > 55
     np.testing.assert_allclose(mom32, g["moment"], rtol=2e-4, atol=2e-6)
+    # ... and the rotor speeds it commands (round 5: rot32 was computed and never asserted).  Compared as w^2 against the size S of the terms the
+    # inverse allocation adds up (tests/fixture_checks.py check_g9_rotor_speeds has the derivation and the float64 / HIP legs)
+    from fixture_checks import _alloc_scale
+    S = _alloc_scale(DqlConfig(), g["cmd"][:, 3], g["moment"])
+    err = np.abs(rot32 ** 2 - g["rotor"] ** 2).max(axis=1) / S
+    assert err[tilt <= 55].max() <= 1e-6 and err.max() <= 5e-5
 
 
 def test_g11_platform(golden_dir):
