@@ -172,7 +172,11 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
             return None
         mean = lambda k: sum(r[k] for r in runs) / len(runs)
         pops = [lv["population_success_at_promotion"] for r in runs for lv in r["levels"] if lv["promoted"]]
-        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"), "mode": "paper-mode MDP, reference update rule (quirks 0x60), one learning-rate step per agent period (Trainer default)",
+        # stage 4 is ENTERED by the rule when levels 0-3 were all promoted by it (not handed over by an exhausted budget, pkg/trainer.py:187)
+        by_rule = [r for r in runs if all(lv["promoted"] for lv in r["levels"][:4]) and len(r["levels"]) > 4]
+        return {"wall_to_stage4_s": mean("wall_to_stage4_s"), "wall_all_levels_s": mean("wall_all_levels_s"),
+                "seeds_reaching_stage4_by_rule": len(by_rule), "n_seeds": len(runs),
+                "wall_to_stage4_by_rule_s": (sum(r["wall_to_stage4_s"] for r in by_rule) / len(by_rule)) if by_rule else None, "mode": "paper-mode MDP, reference update rule (quirks 0x60), one learning-rate step per agent period (Trainer default)",
                 "workload": f"BASELINE configs[3]{' share' if world > 1 or args.curriculum_envs == 32768 else ''}: {args.curriculum_envs} envs per GPU, full curriculum 0 -> 4",
                 "envs_per_gpu": args.curriculum_envs, "global_envs": n_global, "episode_budget_per_level": budget, "sync_period": CURRICULUM_SYNC, "trainer_kw": CURRICULUM_KW,
                 "seeds": [r["seed"] for r in runs], "promoted_levels_per_seed": [r["promoted_levels"] for r in runs],
@@ -246,16 +250,22 @@ def spawn_ranks(args, child_argv=None) -> int:
     return 0
 
 
-def roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec_per_launch, n_launch, k_pairs_ms=None):
+def roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec_per_launch, n_launch, k_pairs_ms=None, valu=None, dtype_name="f32"):
     """`roofline` object of one measurement: achieved = algorithmic bytes per launch / average launch duration (HIP events on the engine's
     stream around the back-to-back launches of the timed region); traffic = HBM bytes per launch from the committed PMC pass of the same
-    configuration AND the same kernel sources, else null."""
+    configuration AND the same kernel sources, else null.  `bound` names the roof that BINDS (VALU issue: the state crosses HBM once per P periods),
+    `frac` stays the north_star's figure — SURVEY.md section 8d's algorithmic bytes against the 8 TB/s peak — and `hbm_real_frac` is what the
+    kernel really draws (counter bytes / time / peak)."""
     ab = algo_bytes(two_axis, randomize_platform)
     ach = ab * dec_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, note = None, None
     prof, src = committed_profile("traffic")
     key = flavour_key(envs, P, two_axis, randomize_platform, noise)
-    if prof is None:
+    if dtype_name != "f32":
+        ab *= 2  # the same 40 / 41 / 50 words of state per env, 8 bytes each
+        ach *= 2
+        note = "no PMC pass of the float64 kernel is committed"
+    elif prof is None:
         note = src
     elif key not in prof["configs"]:
         note = f"profiles/{src} has no pass of configuration {key}"
@@ -263,10 +273,14 @@ def roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec_per_l
         traffic = prof["configs"][key]["hbm_bytes_per_env_step"] * dec_per_launch
         note = (f"profiles/{src} [{key}], same kernel sources ({prof['source_sha16']}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the "
                 "gfx950 correction), HBM bytes per env-step x env-steps per launch of this run")
-    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": note,
+    out = {"bound": "valu_issue", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": note,
+           "frac_is": "hbm_algorithmic", "hbm_real_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and k_ms > 0) else None,
+           "valu_issue_frac": (valu or {}).get("frac_at_2p4_ghz"),
            "kernel": "k_step", "kernel_avg_ms": k_ms, "kernel_launches_timed": n_launch, "agent_periods_per_launch": P,
            "algorithmic_bytes_per_env_step": ab, "env_steps_per_launch": dec_per_launch,
-           "note": "the fused step is VALU-bound (~22 physics ticks per 328 B of state); HBM fraction reported as north_star asks"}
+           "note": "bound = the roof that binds: wave64 VALU issue (~22 physics ticks per 328 B of state; the env stays in registers for P periods, so the real "
+                   "HBM draw is hbm_real_frac).  achieved / peak / frac = the north_star's HBM figure: SURVEY.md 8d algorithmic bytes per env-step x env-steps per "
+                   "launch / launch duration against 8 TB/s; valu_issue_frac = VALU instructions x 2 cycles per SIMD / (duration x 2.4 GHz)"}
     if k_pairs_ms is not None:
         out["kernel_avg_ms_event_pairs"] = k_pairs_ms
     return out
@@ -290,17 +304,17 @@ def single_gpu_block(tag, what, envs, two_axis, randomize_platform, noise, dtype
     dec = s1["decisions"] - s0["decisions"]
     n_launch = -(-steps // P)
     k_ms = dev_ms / n_launch
-    out = {"workload": f"{tag}: {what}", "envs": envs, "value": dec / wall, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
-           "device_ms_per_step": dev_ms / steps, "periods_per_launch": P,
-           "roofline": roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec / n_launch, n_launch)}
     v = valu_issue(envs, P, two_axis, randomize_platform, noise, dtype_name, k_ms, steps / n_launch)
+    out = {"workload": f"{tag}: {what}", "envs": envs, "dtype": dtype_name, "value": dec / wall, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
+           "device_ms_per_step": dev_ms / steps, "periods_per_launch": P,
+           "roofline": roofline_block(envs, P, two_axis, randomize_platform, noise, k_ms, dec / n_launch, n_launch, valu=v, dtype_name=dtype_name)}
     if v:
         out["valu_issue"] = v
     return out
 
 
 DETAIL_FILE = "bench_detail.json"
-LINE_LIMIT = 6000  # bytes: the driver keeps the last 8 KB of stdout; round 3's 26 KB line was cut and did not parse
+LINE_LIMIT = 7000  # bytes: the driver keeps the last 8 KB of stdout; round 3's 26 KB line was cut and did not parse
 
 
 def _pick(d, keys):
@@ -312,6 +326,8 @@ def compact_line(full: dict) -> dict:
     whatever the number of curriculum seeds or ranks.  Everything else (per-seed runs, per-level records, notes, sources, the other sync
     periods) goes to DETAIL_FILE next to this script, which the line names."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "preroll_steps", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    if full.get("repeats"):
+        out["repeats"] = _pick(full["repeats"], ("n", "value_min", "value_max", "ms_per_step_min", "ms_per_step_max", "statistic"))
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, ("workload", "baseline_config", "envs_per_gpu", "global_envs", "sync_period", "periods_per_launch", "parallelism", "exchange_rehearsal",
                                 "algorithmic_bytes_per_env_step", "library_source_sha16"))
@@ -319,8 +335,8 @@ def compact_line(full: dict) -> dict:
     if not out["config"].get("exchange_rehearsal"):
         out["config"].pop("exchange_rehearsal", None)
     out["env_steps"] = full.get("env_steps")
-    roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "kernel_launches_timed", "agent_periods_per_launch",
-                 "algorithmic_bytes_per_env_step", "env_steps_per_launch")
+    roof_keys = ("bound", "achieved", "peak", "unit", "frac", "frac_is", "hbm_real_frac", "valu_issue_frac", "traffic", "kernel", "kernel_avg_ms", "kernel_launches_timed",
+                 "agent_periods_per_launch", "algorithmic_bytes_per_env_step", "env_steps_per_launch")
     out["roofline"] = _pick(full.get("roofline"), roof_keys)
     issue_keys = ("valu_instr_per_env_wave_per_period", "env_waves_per_simd", "cycles_per_instr", "frac_at_2p4_ghz", "measured_clock_ghz", "frac_at_measured_clock")
     if isinstance(full.get("valu_issue"), dict) and "frac_at_2p4_ghz" in full["valu_issue"]:
@@ -333,9 +349,21 @@ def compact_line(full: dict) -> dict:
             if isinstance(b.get("valu_issue"), dict) and "frac_at_2p4_ghz" in b["valu_issue"]:
                 out[blk]["valu_issue_frac_at_2p4_ghz"] = b["valu_issue"]["frac_at_2p4_ghz"]
                 out[blk]["valu_issue_frac_at_measured_clock"] = b["valu_issue"]["frac_at_measured_clock"]
+    if full.get("f64"):
+        b = full["f64"]
+        out["f64"] = {**_pick(b, ("envs", "value", "ms_per_step")), "kernel_avg_ms": b["roofline"]["kernel_avg_ms"],
+                      "roofline": _pick(b["roofline"], ("bound", "achieved", "peak", "unit", "frac", "hbm_real_frac", "traffic"))}
+    if full.get("eps_0p1"):
+        out["eps_0p1"] = _pick(full["eps_0p1"], ("eps", "value", "ms_per_step", "kernel_avg_ms", "roofline_frac", "value_min", "value_max"))
     if full.get("sync"):
-        out["sync"] = _pick(full["sync"], ("sync_period", "ms_per_step", "ms_per_step_no_exchange", "sync_ms_per_step", "exchange_device_ms", "exchanges_timed",
-                                           "staleness_bound_periods", "p2p_failed"))
+        out["sync"] = _pick(full["sync"], ("exchange_name", "sync_period", "ms_per_step", "ms_per_step_no_exchange", "sync_ms_per_step", "exchange_device_ms", "exchanges_timed",
+                                           "staleness_bound_periods", "replicas_identical", "p2p_failed"))
+        for other in ("p2p", "rccl"):
+            if isinstance(full["sync"].get(other), dict):
+                o = full["sync"][other]
+                out["sync"][other] = _pick(o, ("value", "ms_per_step", "sync_ms_per_step", "exchange_device_ms", "replicas_identical"))
+                if "skipped" in o:
+                    out["sync"][other]["skipped"] = str(o["skipped"])[:200]
         out["sync_ms_per_step"] = full["sync"].get("sync_ms_per_step")
     cur = full.get("curriculum")
     if cur is not None:
@@ -343,7 +371,8 @@ def compact_line(full: dict) -> dict:
             out["curriculum"] = {"error": str(cur["error"])[:300]}
         else:
             pop = cur.get("population_success_at_promotion") or {}
-            out["curriculum"] = {**_pick(cur, ("wall_to_stage4_s", "wall_all_levels_s", "envs_per_gpu", "global_envs", "sync_period", "seeds", "promoted_levels_per_seed")),
+            out["curriculum"] = {**_pick(cur, ("wall_to_stage4_s", "wall_all_levels_s", "seeds_reaching_stage4_by_rule", "n_seeds", "wall_to_stage4_by_rule_s", "envs_per_gpu",
+                                               "global_envs", "sync_period", "seeds", "promoted_levels_per_seed")),
                                  "population_success_at_promotion": _pick(pop, ("min", "mean")),
                                  "stage4_greedy_4096_episodes": _pick(cur.get("stage4_greedy_4096_episodes"), ("trained_mean", "trained_worst_seed", "reference_assets"))}
             out.update(_pick(full, ("promoted_levels", "goal_hold_rate", "touchdown_rate", "wall_to_stage4_s")))
@@ -353,7 +382,7 @@ def compact_line(full: dict) -> dict:
     out["reference_quoted"] = _pick(full.get("reference_quoted"), ("reference+gazebo_env_steps_per_s", "realtime_ceiling", "reference_python_mdp+agent_steps_per_s"))
     out["detail_file"] = DETAIL_FILE
     # last resort, never expected: shed optional blocks rather than print a line the driver cannot parse
-    for k in ("reference_quoted", "large_batch", "small_batch", "valu_issue", "sync", "curriculum"):
+    for k in ("reference_quoted", "large_batch", "small_batch", "eps_0p1", "valu_issue", "f64", "sync", "curriculum"):
         if len(json.dumps(out)) <= LINE_LIMIT:
             break
         out.pop(k, None)
@@ -383,6 +412,9 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (weak scaling); overrides the preset")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eps", type=float, default=1.0)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region (exactly K steps between barrier + device sync) is run this many times back to back; `value` / `ms_per_step` / the roofline are the "
+                         "MEDIAN repetition's, min and max next to them (a single 20-step region is 0.5 ms: one draw says little)")
     ap.add_argument("--sync-period", type=int, default=16,
                     help="agent periods between table exchanges (N > 1).  Default 16 = periods per launch: the smallest window that costs no extra launch boundary; "
                          "a rank then acts on tables that miss at most the other ranks' last 16 + 16 (one-launch fold delay) + 16 (window in flight) = 48 periods")
@@ -402,6 +434,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=600, help="agent periods of the single-thread CPU sample (x cores for the all-core sample): ~5 s + ~7 s")
     ap.add_argument("--small-envs", type=int, default=4096, help="secondary single-GPU block at BASELINE configs[1] (0 = skip)")
     ap.add_argument("--large-envs", type=int, default=1048576, help="secondary single-GPU block at a chip-filling batch (0 = skip)")
+    ap.add_argument("--no-f64-block", dest="f64_block", action="store_false", help="skip the float64 block of the single-GPU line (same workload in the reference's precision)")
     ap.add_argument("--no-curriculum", action="store_true", help="skip the wall-clock-to-stage-4 leg")
     ap.add_argument("--curriculum-envs", type=int, default=32768, help="envs per GPU of the curriculum leg (BASELINE configs[3]: 262 144 / 8)")
     ap.add_argument("--curriculum-seeds", type=int, default=None,
@@ -461,9 +494,27 @@ def main():
         print("bench.py: --periods-per-launch must be in 1..16", file=sys.stderr)
         sys.exit(2)
     eng.set_option("periods_per_launch", args.periods_per_launch)
-    reducer = None
+    # BOTH exchanges are set up on the one engine (round 5): the run's `value` is timed with --exchange (default RCCL), the other one gets its own
+    # timed leg in the same run (sync.<name> block) — one `bench.py --gpus 8` answers which is faster.  The peer-to-peer set-up may be refused
+    # (HIP IPC between these devices): then its leg is reported as skipped, with the reason; its wait is bounded (p2p_spin_limit), never a hang.
+    reducers, p2p_setup_error = {}, None
     if multi:
-        reducer = P2PWindowReducer(eng, rank, world) if args.exchange == "p2p" else RcclWindowReducer(eng, comm)
+        reducers["rccl"] = RcclWindowReducer(eng, comm)
+        try:
+            eng.set_option("p2p_spin_limit", 4000000)  # ~ seconds: a peer that never shows up ends the leg, not the job's time limit
+            reducers["p2p"] = P2PWindowReducer(eng, rank, world)
+        except Exception as e:  # noqa: BLE001
+            p2p_setup_error = f"{type(e).__name__}: {e}"[:300]
+        ok = float("p2p" in reducers)
+        if comm and world > 1:  # on every rank or on none
+            ok = float(-comm.all_reduce_max([-ok])[0])
+        if not ok:
+            reducers.pop("p2p", None)
+            p2p_setup_error = p2p_setup_error or "the peer-to-peer exchange could not be set up on another rank"
+        if args.exchange == "p2p" and "p2p" not in reducers:
+            print(f"bench.py rank {rank}: --exchange p2p: {p2p_setup_error}", file=sys.stderr)
+            sys.exit(3)
+    reducer = reducers.get(args.exchange)
 
     def barrier():
         eng.sync()
@@ -471,53 +522,133 @@ def main():
             comm.barrier()
             eng.sync()
 
-    def timed(sync_period, steps, warmup, final_exchange=True):
-        """W untimed + exactly `steps` timed agent periods, barrier + device sync on both sides, MAX over ranks / SUM of env-steps.
-        The timed region ends on exchanged tables (a window still open after `steps` periods is exchanged inside the clock) unless
-        final_exchange is False (the no-exchange yardstick)"""
-        runner = ShardedRunner(eng, reducer, sync_period=sync_period)
-        runner.train_steps(warmup, args.eps)
-        runner.sync()
-        barrier()
-        s0 = eng.stats()
-        eng.timer_start()
-        t0 = time.perf_counter()
-        runner.train_steps(steps, args.eps)
-        if final_exchange:
+    def timed(sync_period, steps, warmup, final_exchange=True, red="default", reps=1, eps=None):
+        """W untimed + `reps` x exactly `steps` timed agent periods — every repetition bracketed by barrier + device sync on both sides, MAX over
+        ranks / SUM of env-steps per repetition.  A repetition ends on exchanged tables (a window still open after `steps` periods is exchanged
+        inside the clock) unless final_exchange is False (the no-exchange yardstick).  Returns [(wall_s, env_steps, device_ms)] per repetition;
+        a rank on which the GPU part raised (a peer-to-peer exchange that gave up) still takes part in every collective and the result is None."""
+        eps = args.eps if eps is None else eps
+        runner = ShardedRunner(eng, reducer if red == "default" else red, sync_period=sync_period)
+        out, failed = [], 0.0
+        try:
+            runner.train_steps(warmup, eps)
             runner.sync()
-        dev_ms = eng.timer_stop()          # waits for the stream: this rank's K steps are done
-        wall = time.perf_counter() - t0    # (MAX over ranks below = the job's time)
-        runner.sync()
-        barrier()
-        s1 = eng.stats()
-        dec = s1["decisions"] - s0["decisions"]
-        if comm:
-            wall = float(comm.all_reduce_max([wall])[0]); dec = int(comm.all_reduce_sum([float(dec)])[0])
-        return wall, dec, dev_ms
+        except Exception as e:  # noqa: BLE001
+            failed = 1.0; print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+        for _ in range(reps):
+            barrier()
+            wall = dev_ms = 0.0; dec = 0
+            if not failed:
+                try:
+                    s0 = eng.stats()
+                    eng.timer_start()
+                    t0 = time.perf_counter()
+                    runner.train_steps(steps, eps)
+                    if final_exchange:
+                        runner.sync()
+                    dev_ms = eng.timer_stop()          # waits for the stream: this rank's K steps are done
+                    wall = time.perf_counter() - t0    # (MAX over ranks below = the job's time)
+                    runner.sync()
+                    eng.sync()
+                    dec = eng.stats()["decisions"] - s0["decisions"]
+                except Exception as e:  # noqa: BLE001
+                    failed = 1.0; print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            barrier()
+            if comm:
+                wall, failed = (float(x) for x in comm.all_reduce_max([wall, failed])); dec = int(comm.all_reduce_sum([float(dec)])[0])
+            out.append((wall, dec, dev_ms))
+        return None if failed else out
+
+    def median_rep(rs):
+        """(wall, env_steps, device_ms) of the repetition with the median throughput + the spread over the repetitions"""
+        order = sorted(range(len(rs)), key=lambda i: rs[i][1] / rs[i][0])
+        m = rs[order[len(order) // 2]]
+        vals = [r[1] / r[0] for r in rs]
+        return m, {"n": len(rs), "value_min": min(vals), "value_max": max(vals), "ms_per_step_min": min(r[0] for r in rs) * 1e3 / args.steps,
+                   "ms_per_step_max": max(r[0] for r in rs) * 1e3 / args.steps, "statistic": "median over back-to-back repetitions of the K-step timed region"}
+
+    def tables_hash():
+        """6 x 32 bits of SHA-256 over the three tables (as exact float64 values for the max / min all-reduce)"""
+        qa, qb, cnt = eng.get_tables()
+        h = hashlib.sha256(qa.tobytes() + qb.tobytes() + cnt.tobytes()).digest()
+        return [float(int.from_bytes(h[4 * i:4 * i + 4], "little")) for i in range(6)]
+
+    def replicas_identical():
+        """after an exchange: do all ranks hold the same tables?  all-reduce(max) and all-reduce(min) of the table hash must agree"""
+        h = tables_hash()
+        if not comm or world == 1:
+            return True
+        hi = comm.all_reduce_max(h); lo = -comm.all_reduce_max([-x for x in h])
+        return bool((hi == lo).all())
 
     # pre-roll + W warm-up periods, all untimed, all on the run's own table schedule (exchanges included with several ranks)
-    wall, decisions, dev_ms = timed(args.sync_period, args.steps, args.preroll + args.warmup)
+    reps = timed(args.sync_period, args.steps, args.preroll + args.warmup, reps=max(1, args.repeats))
+    if reps is None:
+        print(f"bench.py rank {rank}: the timed region failed", file=sys.stderr)
+        sys.exit(4)
+    (wall, decisions, dev_ms), spread = median_rep(reps)
     sync_info = None
     if multi:
+        identical = replicas_identical()   # the timed region ended on exchanged tables: every rank must hold the same three tables now
+        EXCHANGE_TEXT = {"p2p": "flush + push of 11 340 int64 words into every rank's exchange buffer (HIP IPC, uncached) + flags + local sum + fold, on the engine's stream",
+                         "rccl": "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream"}
         # the exchange's price: same region without exchanges (one window, folded after the clock stops: NOT a valid training
         # schedule, a yardstick), and at sync_period 2 (the regime in which the run does not depend on the number of ranks)
-        w_none, d_none, _ = timed(args.steps + args.warmup + 1, args.steps, 0, final_exchange=False)
+        r_none = timed(args.steps + args.warmup + 1, args.steps, 0, final_exchange=False, reps=3)
+        (w_none, d_none, _), _sp = median_rep(r_none)
         others = {}
         for sp in (2, 16, 32):
             if sp != args.sync_period:
-                w_sp, d_sp, _ = timed(sp, args.steps, 0)
+                (w_sp, d_sp, _), _s = median_rep(timed(sp, args.steps, 0, reps=3))
                 others[f"sync_period_{sp}"] = {"value": d_sp / w_sp, "ms_per_step": w_sp * 1e3 / args.steps, "sync_ms_per_step": (w_sp - w_none) * 1e3 / args.steps}
-        eng.kernel_timer(True)
-        r2 = ShardedRunner(eng, reducer, sync_period=args.sync_period); r2.train_steps(4 * args.sync_period, args.eps); r2.sync()
-        sync_dev_ms, n_sync = eng.sync_time_ms()
-        eng.kernel_timer(False)
-        sync_info = {"sync_period": args.sync_period, "ms_per_step": wall * 1e3 / args.steps, "ms_per_step_no_exchange": w_none * 1e3 / args.steps,
+
+        def exchange_device_ms(red):
+            eng.kernel_timer(True)
+            r2 = ShardedRunner(eng, red, sync_period=args.sync_period); r2.train_steps(4 * args.sync_period, args.eps); r2.sync()
+            ms, n_ = eng.sync_time_ms()
+            eng.kernel_timer(False)
+            return ms, n_
+        sync_dev_ms, n_sync = exchange_device_ms(reducer)
+        sync_info = {"exchange_name": args.exchange, "sync_period": args.sync_period, "ms_per_step": wall * 1e3 / args.steps, "ms_per_step_no_exchange": w_none * 1e3 / args.steps,
                      "sync_ms_per_step": (wall - w_none) * 1e3 / args.steps, "exchange_device_ms": sync_dev_ms, "exchanges_timed": n_sync,
                      "staleness_bound_periods": args.sync_period + 2 * max(args.sync_period, args.periods_per_launch),
                      "staleness_note": "a rank acts on tables that hold every rank's updates older than this many agent periods: the window in flight, the launch whose accumulators are being folded, and the launch in progress",
-                     "exchange": ("flush + push of 11 340 int64 words into every rank's exchange buffer (HIP IPC, uncached) + flags + local sum + fold, on the engine's stream"
-                                  if args.exchange == "p2p" else "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream"),
-                     "p2p_failed": eng.p2p_failed() if args.exchange == "p2p" else None, **others}
+                     "exchange": EXCHANGE_TEXT[args.exchange], "replicas_identical": identical, **others}
+        # the OTHER exchange, same engine, same schedule, same run (its failure ends its leg, not the run: the line's value is already measured)
+        other = "p2p" if args.exchange == "rccl" else "rccl"
+        if other not in reducers:
+            sync_info[other] = {"skipped": p2p_setup_error}
+        else:
+            r_o = timed(args.sync_period, args.steps, args.warmup, red=reducers[other], reps=max(3, args.repeats // 2))
+            if r_o is None:
+                sync_info[other] = {"skipped": "the exchange failed inside its timed leg (a peer was not seen within p2p_spin_limit polls); see stderr"}
+            else:
+                (w_o, d_o, _), sp_o = median_rep(r_o)
+                ident_o = replicas_identical()
+                ms_o, n_o = exchange_device_ms(reducers[other])
+                sync_info[other] = {"value": d_o / w_o, "ms_per_step": w_o * 1e3 / args.steps, "sync_ms_per_step": (w_o - w_none) * 1e3 / args.steps, "exchange_device_ms": ms_o,
+                                    "exchanges_timed": n_o, "replicas_identical": ident_o, "value_min": sp_o["value_min"], "value_max": sp_o["value_max"], "exchange": EXCHANGE_TEXT[other]}
+        if "p2p" in reducers:
+            try:
+                sync_info["p2p_failed"] = eng.p2p_failed()
+            except Exception:  # noqa: BLE001
+                sync_info["p2p_failed"] = True
+        if not identical:
+            print(f"bench.py rank {rank}: the table replicas DIFFER between ranks after the final exchange ({args.exchange}): the run is invalid", file=sys.stderr)
+            if comm:
+                comm.barrier(); comm.close()
+            sys.exit(5)
+
+    # SURVEY.md section 8d config 2 asks "eps = 1.0 then 0.1": the same engine carries on at eps = 0.1 on the tables it has learnt so far (longer
+    # episodes, fewer resets, greedy choices from the table rows): a second, shorter timed leg
+    eps01 = None
+    if not multi and abs(args.eps - 0.1) > 1e-12:
+        r01 = timed(args.sync_period, args.steps, args.warmup, reps=3, eps=0.1)
+        if r01 is not None:
+            (w01, d01, ms01), sp01 = median_rep(r01)
+            eps01 = {"eps": 0.1, "value": d01 / w01, "ms_per_step": w01 * 1e3 / args.steps, "kernel_avg_ms": ms01 / -(-args.steps // args.periods_per_launch),
+                     "value_min": sp01["value_min"], "value_max": sp01["value_max"], "env_steps": d01,
+                     "note": "same engine, right after the eps = 1.0 region, training continued at eps = 0.1 on the tables learnt so far"}
 
     # Average launch duration of the fused step kernel, HIP events on the engine's stream.  One rank: the step kernel is the
     # only kernel between the two events of the timed region (K launches back to back), so duration = region / K — the figure
@@ -558,8 +689,7 @@ def main():
                        "parallelism": f"env-shard x{world}" + ((", one-shot peer-to-peer window exchange (libdql_hip.so, HIP IPC)" if args.exchange == "p2p" else ", RCCL int64 window all-reduce (libdql_hip.so, no PyTorch)") if multi else ""), "block": args.block,
                        "two_axis": args.two_axis, "randomize_platform": args.randomize_platform, "noise": args.noise, "algorithmic_bytes_per_env_step": ab,
                        "library_source_sha16": lib_source_sha16()},
-            "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps,
-            "roofline": roofline_block(args.envs, P, args.two_axis, args.randomize_platform, args.noise, k_ms, dec_per_launch, n_launch if not multi else k_n, k_pairs_ms),
+            "env_steps": decisions, "device_ms_per_step": dev_ms / args.steps, "repeats": spread,
             "reference_quoted": {"reference+gazebo_env_steps_per_s": 20.18, "realtime_ceiling": 22.92,
                                  "reference_python_mdp+agent_us_per_step": 69.6, "reference_python_mdp+agent_steps_per_s": 14.4e3,
                                  "source": "BASELINE.md section 2 (artefact-derived / measured in the survey container on 1 core; not re-measurable on the GPU box)"},
@@ -570,11 +700,19 @@ def main():
         valu = valu_issue(args.envs, P, args.two_axis, args.randomize_platform, args.noise, args.dtype, k_ms, args.steps / n_launch if not multi else P)
         if valu:
             out["valu_issue"] = valu
+        out["roofline"] = roofline_block(args.envs, P, args.two_axis, args.randomize_platform, args.noise, k_ms, dec_per_launch, n_launch if not multi else k_n, k_pairs_ms, valu)
+        if eps01:
+            eps01["roofline_frac"] = ab * eps01["env_steps"] / -(-args.steps // P) / (eps01["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            out["eps_0p1"] = eps01
         if not multi:
             # secondary single-GPU blocks, each with its own roofline from stream events of THIS run
             if args.small_envs > 0 and not (args.envs == args.small_envs and not custom and args.config == 1):
                 p1 = PRESETS[1]
                 out["small_batch"] = single_gpu_block(p1["tag"], p1["what"], args.small_envs, 0, 0, 0, dtype, args.dtype, P, args.eps, max(args.steps, 400), max(args.warmup, 40), dev_index)
+            # the precision at which parity with the reference is BIT-EXACT (pkg/mdp.py:11-32 and everything behind it is float64): same workload, float64 kernel
+            if args.dtype == "f32" and args.f64_block:
+                out["f64"] = single_gpu_block(tag + " in float64 (the reference's precision: reference == oracle == kernel bit for bit)", pre["short"] if not custom else "custom", args.envs,
+                                              args.two_axis, args.randomize_platform, args.noise, F64, "f64", P, args.eps, 10 * P, 2 * P, dev_index)
             if args.large_envs > 0 and args.envs != args.large_envs:
                 out["large_batch"] = single_gpu_block("chip-filling batch (= configs[4] on ONE GPU)", "1 048 576 envs, per-env randomised platforms + observation noise" if args.large_envs == 1048576 else f"{args.large_envs} envs, per-env randomised platforms + observation noise",
                                                       args.large_envs, 0, 1, 1, dtype, args.dtype, P, args.eps, 40 * P, 5 * P, dev_index)

@@ -246,6 +246,7 @@ template <typename T> struct MdpK {
   T w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   T lim_p[5], lim_v[5], lim_a[5], angles[7];
   T inv_p_max, inv_v_max, inv_a_max, inv_theta_max, dtheta_ratio;  // float32 MDP (round 4): reciprocals of the normalising constants, delta_theta / theta_max
+  T tan2_mid[3];  // float32 fused step (round 5): tan^2 of the three bin boundaries of the angle grid on either side of zero (angle_bin_from_tangent)
   double gamma;
   int working, goal_logic;
   uint32_t quirks;
@@ -346,6 +347,9 @@ struct LitM {
 #define DQL_G(n, a, b, c, d, e, f, g) static constexpr float n[7] = {a, b, c, d, e, f, g};
   DQL_REFM_GRID(DQL_G)
 #undef DQL_G
+#define DQL_T(n, a, b, c) static constexpr float n[3] = {a, b, c};
+  DQL_REFM_TAN2(DQL_T)
+#undef DQL_T
   float timeout_steps; double gamma; int working, goal_logic; uint32_t quirks;
 };
 
@@ -400,8 +404,8 @@ template <typename T> DQL_DEV T norm_by(T x, T d, T inv) {
   if constexpr (sizeof(T) == 4) return x * inv;
   else return x / d;
 }
-// M: MdpK<T> (run-time constants) or LitM (the reference MDP as literals, float32)
-template <typename M, typename T> DQL_DEV int discretise(const M& m, T rel_p, T rel_v, T rel_a, T angle) {  // :257-333
+// M: MdpK<T> (run-time constants) or LitM (the reference MDP as literals, float32); BIN_GIVEN: the angle's grid bin is passed in (angle_bin_from_tangent)
+template <bool BIN_GIVEN, typename M, typename T> DQL_DEV int discretise_impl(const M& m, T rel_p, T rel_v, T rel_a, T angle, int angle_bin) {  // :257-333
   const T cp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
   const T cv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T ca = clip(norm_by(rel_a, m.a_max, m.inv_a_max), T(-1.0), T(1.0));
@@ -419,11 +423,31 @@ template <typename M, typename T> DQL_DEV int discretise(const M& m, T rel_p, T 
   const int dv = disc3(cv, lv * vc, lv);
   const int da = disc3(ca, la * ac, la);
   if (dp < 0 || dv < 0 || da < 0) return -1;
-  const T ct = clip(angle, -T(m.theta_max), T(m.theta_max));
-  int best = 0; T bd = abs_(T(m.angles[0]) - ct);
+  int best;
+  if constexpr (BIN_GIVEN) best = angle_bin;
+  else {
+    const T ct = clip(angle, -T(m.theta_max), T(m.theta_max));
+    best = 0; T bd = abs_(T(m.angles[0]) - ct);
 #pragma unroll
-  for (int i = 1; i < 7; ++i) { const T d = abs_(T(m.angles[i]) - ct); if (d < bd) { bd = d; best = i; } }
+    for (int i = 1; i < 7; ++i) { const T d = abs_(T(m.angles[i]) - ct); if (d < bd) { bd = d; best = i; } }
+  }
   return (((k * 3 + dp) * 3 + dv) * 3 + da) * 7 + best;
+}
+template <typename M, typename T> DQL_DEV int discretise(const M& m, T rel_p, T rel_v, T rel_a, T angle) { return discretise_impl<false>(m, rel_p, rel_v, rel_a, angle, 0); }
+// FLOAT32 FUSED STEP, ROUND 5.  The step needs the Euler angle only to pick the nearest of the seven grid angles -theta_max .. theta_max
+// (pkg/mdp.py:145, 318-324: argmin |grid - clip(angle)|, first minimum).  The nearest grid angle changes at the six midpoints +-(j + 1/2) step, and an
+// angle given as atan2(s, c) with c >= 0 lies beyond a midpoint mu exactly when tan^2 = s^2 / c^2 exceeds tan^2(mu) on that side — so the bin is three
+// comparisons of s^2 with tan2_mid[j] c^2 and a sign: ~12 instructions instead of a square root, a division, an arctangent and the argmin (~110).
+// Ties go where the reference's first-minimum rule sends them (towards zero on the positive side, away from it on the negative side).  c2 = c^2 (for the
+// pitch: R00^2 + R10^2 = cos^2, no root needed); c_pos: c > 0 (a roll beyond 90 deg has c <= 0: the clip puts it into the outermost bin).
+template <typename M> DQL_DEV int angle_bin_from_tangent(const M& m, float s, float c2, bool c_pos) {
+  const float s2 = s * s;
+  const float t0 = float(m.tan2_mid[0]) * c2, t1 = float(m.tan2_mid[1]) * c2, t2 = float(m.tan2_mid[2]) * c2;
+  const bool neg = s < 0.0f;
+  const bool b0 = neg ? s2 >= t0 : s2 > t0, b1 = neg ? s2 >= t1 : s2 > t1, b2 = neg ? s2 >= t2 : s2 > t2;
+  int c = b2 ? 3 : (b1 ? 2 : (b0 ? 1 : 0));
+  if (!c_pos) c = (s != 0.0f) ? 3 : 0;
+  return neg ? 3 - c : 3 + c;
 }
 DQL_DEV int idx_level(int idx) { return idx / DQL_STATES_PER_LEVEL; }
 DQL_DEV int idx_pos(int idx) { return (idx / 63) % 3; }
@@ -1264,16 +1288,27 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
   T R[9];
   DQL_SECTION("end_pitch");
   quat_to_R(e.q, R);
-  const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
-  const T pitch = det_atan2(-R[6], cyy);
-  DQL_SECTION("end_discretise");
-  int idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
+  int idx, idy = -1;
+#ifdef DQL_AB_NO_TANBIN  // A/B builds (tools/ab_build.sh): timing only, no parity
+  constexpr bool TANBIN = false;
+#else
+  constexpr bool TANBIN = Fast32<T>::on;
+#endif
+  if constexpr (TANBIN) {  // the angle bins straight from the rotation matrix (angle_bin_from_tangent): pitch = atan2(-R20, sqrt(R00^2 + R10^2)), roll = atan2(R21, R22)
+    const int bin_x = angle_bin_from_tangent(m, -R[6], fma_(R[0], R[0], R[3] * R[3]), true);
+    DQL_SECTION("end_discretise");
+    idx = discretise_impl<true>(m, e.obs_px, e.obs_vx, e.obs_ax, T(0.0), bin_x);
+    if (two) idy = discretise_impl<true>(m, e.obs_py, e.obs_vy, e.obs_ay, T(0.0), angle_bin_from_tangent(m, -R[7], R[8] * R[8], R[8] > T(0.0)));
+  } else {
+    const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
+    const T pitch = det_atan2(-R[6], cyy);
+    DQL_SECTION("end_discretise");
+    idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
+    if (two) { const T roll = det_atan2(R[7], R[8]); idy = discretise(m, e.obs_py, e.obs_vy, e.obs_ay, -roll); }
+  }
   if (idx < 0) idx = 0;
   e.idx_x = idx;
-  int idy = -1;
   if (two) {
-    const T roll = det_atan2(R[7], R[8]);
-    idy = discretise(m, e.obs_py, e.obs_vy, e.obs_ay, -roll);
     if (idy < 0) idy = 0;
     e.idx_y = idy;
   }

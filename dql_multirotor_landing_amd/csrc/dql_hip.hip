@@ -61,6 +61,7 @@ template <typename T> static MdpK<T> make_mdpk(const dql_config& c) {
   d.angles[6] = (T)c.theta_max;
   d.inv_p_max = (T)(1.0 / c.p_max); d.inv_v_max = (T)(1.0 / c.v_max); d.inv_a_max = (T)(1.0 / c.a_max);
   d.inv_theta_max = (T)(1.0 / c.theta_max); d.dtheta_ratio = (T)(c.delta_theta / c.theta_max);
+  for (int j = 0; j < 3; ++j) { const double t = std::tan(((double)j + 0.5) * step); d.tan2_mid[j] = (T)(t * t); }  // bin boundaries of the angle grid (angle_bin_from_tangent)
   d.gamma = c.gamma; d.working = c.working_curriculum_step; d.goal_logic = c.goal_logic; d.quirks = c.quirks;
   return d;
 }
@@ -92,6 +93,9 @@ static bool refm_matches(const MdpK<float>& m) {
 #define DQL_G(n, a, b, c, d, e, f, g) { const float r[7] = {a, b, c, d, e, f, g}; ok = ok && memcmp(m.n, r, sizeof(r)) == 0; }
   DQL_REFM_GRID(DQL_G)
 #undef DQL_G
+#define DQL_T(n, a, b, c) { const float r[3] = {a, b, c}; ok = ok && memcmp(m.n, r, sizeof(r)) == 0; }
+  DQL_REFM_TAN2(DQL_T)
+#undef DQL_T
   return ok;
 }
 // P's fixed point under kalman1d's update in T arithmetic (P += Q; K = P / (P + R); P *= 1 - K), reached from the creation value P = 1; pss = NaN when

@@ -264,6 +264,7 @@ typedef struct {
   REAL w_p, w_v, w_theta, w_dur, w_fail, w_succ, delta_t, f_ag, timeout_steps;
   REAL lim_p[5], lim_v[5], lim_a[5], angles[7];
   REAL inv_p_max, inv_v_max, inv_a_max, inv_theta_max, dtheta_ratio; /* float32 MDP: host reciprocals (round 4) */
+  REAL tan2_mid[3]; /* float32 fused step (round 5): tan^2 of the angle grid's bin boundaries (angle_bin_from_tangent) */
   int working, goal_logic;
   uint32_t quirks;
 } mdpc_t;
@@ -283,6 +284,7 @@ static void mdpc_init(mdpc_t* m, const dql_config* c) {
   m->angles[6] = (REAL)c->theta_max;
   m->inv_p_max = (REAL)(1.0 / c->p_max); m->inv_v_max = (REAL)(1.0 / c->v_max); m->inv_a_max = (REAL)(1.0 / c->a_max);
   m->inv_theta_max = (REAL)(1.0 / c->theta_max); m->dtheta_ratio = (REAL)(c->delta_theta / c->theta_max);
+  for (int j = 0; j < 3; ++j) { const double t = tan(((double)j + 0.5) * step); m->tan2_mid[j] = (REAL)(t * t); }
   m->working = c->working_curriculum_step; m->goal_logic = c->goal_logic;
   m->quirks = c->quirks;
 }
@@ -337,7 +339,22 @@ static inline int disc3(REAL v, REAL goal, REAL limit) {
   return -1;
 }
 /* pkg/mdp.py:257-333 -> packed index ((((k*3+p)*3+v)*3+a)*7+theta), or -1 */
-static int discretise(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL angle) {
+/* bin_given >= 0: the angle's grid bin comes from angle_bin_from_tangent (float32 fused step), the angle argument is not read */
+static int discretise_bin(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL angle, int bin_given);
+static int discretise(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL angle) { return discretise_bin(m, rel_p, rel_v, rel_a, angle, -1); }
+#if ORACLE_F32
+/* csrc/dql_device.hpp angle_bin_from_tangent: the nearest grid angle of atan2(s, c), c^2 = c2, from three comparisons of s^2 with tan^2(boundary) c^2 */
+static int angle_bin_from_tangent(const mdpc_t* m, REAL s, REAL c2, int c_pos) {
+  const REAL s2 = s * s;
+  const REAL t0 = m->tan2_mid[0] * c2, t1 = m->tan2_mid[1] * c2, t2 = m->tan2_mid[2] * c2;
+  const int neg = s < R_(0.0);
+  const int b0 = neg ? s2 >= t0 : s2 > t0, b1 = neg ? s2 >= t1 : s2 > t1, b2 = neg ? s2 >= t2 : s2 > t2;
+  int c = b2 ? 3 : (b1 ? 2 : (b0 ? 1 : 0));
+  if (!c_pos) c = (s != R_(0.0)) ? 3 : 0;
+  return neg ? 3 - c : 3 + c;
+}
+#endif
+static int discretise_bin(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL angle, int bin_given) {
   const REAL cp = clip(NORM(rel_p, m->p_max, m->inv_p_max), R_(-1.0), R_(1.0));
   const REAL cv = clip(NORM(rel_v, m->v_max, m->inv_v_max), R_(-1.0), R_(1.0));
   const REAL ca = clip(NORM(rel_a, m->a_max, m->inv_a_max), R_(-1.0), R_(1.0));
@@ -353,9 +370,12 @@ static int discretise(const mdpc_t* m, REAL rel_p, REAL rel_v, REAL rel_a, REAL 
   const int dv = disc3(cv, m->lim_v[k] * vc, m->lim_v[k]);
   const int da = disc3(ca, m->lim_a[k] * ac, m->lim_a[k]);
   if (dp < 0 || dv < 0 || da < 0) return -1;
-  const REAL ct = clip(angle, -m->theta_max, m->theta_max);
-  int best = 0; REAL bd = FABS(m->angles[0] - ct);
-  for (int i = 1; i < 7; ++i) { const REAL d = FABS(m->angles[i] - ct); if (d < bd) { bd = d; best = i; } } /* np.argmin: first minimum */
+  int best = bin_given;
+  if (bin_given < 0) {
+    const REAL ct = clip(angle, -m->theta_max, m->theta_max);
+    best = 0; REAL bd = FABS(m->angles[0] - ct);
+    for (int i = 1; i < 7; ++i) { const REAL d = FABS(m->angles[i] - ct); if (d < bd) { bd = d; best = i; } } /* np.argmin: first minimum */
+  }
   return (((k * 3 + dp) * 3 + dv) * 3 + da) * 7 + best;
 }
 static inline int idx_level(int idx) { return idx / DQL_STATES_PER_LEVEL; }
@@ -939,16 +959,20 @@ static void env_agent_period(const simc_t* s, const mdpc_t* m, env_t* e, const d
   }
   /* euler_from_quaternion, axes sxyz (pkg/landing_simulation_env.py:259-267) */
   quat_to_R(e->q, R);
+  /* discrete_state (pkg/mdp.py:257-333) on the latest latched Observation + fresh pitch / altitude */
+  int idx, idy = -1;
+#if ORACLE_F32 /* round 5: the angle bins straight from the rotation matrix (pitch = atan2(-R20, sqrt(R00^2 + R10^2)), roll = atan2(R21, R22)) */
+  idx = discretise_bin(m, e->obs[0], e->obs[2], e->obs[4], R_(0.0), angle_bin_from_tangent(m, -R[6], FMA(R[0], R[0], R[3] * R[3]), 1));
+  if (two) idy = discretise_bin(m, e->obs[1], e->obs[3], e->obs[5], R_(0.0), angle_bin_from_tangent(m, -R[7], R[8] * R[8], R[8] > R_(0.0)));
+#else
   const REAL cyy = SQRT(FMA(R[0], R[0], R[3] * R[3]));
   const REAL pitch = det_atan2(-R[6], cyy);
-  /* discrete_state (pkg/mdp.py:257-333) on the latest latched Observation + fresh pitch / altitude */
-  int idx = discretise(m, e->obs[0], e->obs[2], e->obs[4], pitch);
+  idx = discretise(m, e->obs[0], e->obs[2], e->obs[4], pitch);
+  if (two) { const REAL roll = det_atan2(R[7], R[8]); idy = discretise(m, e->obs[1], e->obs[3], e->obs[5], -roll); }
+#endif
   if (idx < 0) idx = 0; /* only reachable through NaN; the reference raises ValueError there */
   e->idx[0] = idx;
-  int idy = -1;
   if (two) {
-    const REAL roll = det_atan2(R[7], R[8]);
-    idy = discretise(m, e->obs[1], e->obs[3], e->obs[5], -roll);
     if (idy < 0) idy = 0;
     e->idx[1] = idy;
   }
