@@ -465,7 +465,7 @@ def main():
     g.build_hip()
     from dql_multirotor_landing_amd.comm import RcclComm
     from dql_multirotor_landing_amd.config import DqlConfig, F32, F64
-    from dql_multirotor_landing_amd.dist import P2PWindowReducer, RcclWindowReducer, ShardedRunner
+    from dql_multirotor_landing_amd.dist import P2PWindowReducer, RcclWindowReducer, ShardedRunner, median_repetition, replicas_identical, timed_region
     from dql_multirotor_landing_amd.engine import Engine
 
     dtype = F32 if args.dtype == "f32" else F64
@@ -523,63 +523,14 @@ def main():
             eng.sync()
 
     def timed(sync_period, steps, warmup, final_exchange=True, red="default", reps=1, eps=None):
-        """W untimed + `reps` x exactly `steps` timed agent periods — every repetition bracketed by barrier + device sync on both sides, MAX over
-        ranks / SUM of env-steps per repetition.  A repetition ends on exchanged tables (a window still open after `steps` periods is exchanged
-        inside the clock) unless final_exchange is False (the no-exchange yardstick).  Returns [(wall_s, env_steps, device_ms)] per repetition;
-        a rank on which the GPU part raised (a peer-to-peer exchange that gave up) still takes part in every collective and the result is None."""
-        eps = args.eps if eps is None else eps
-        runner = ShardedRunner(eng, reducer if red == "default" else red, sync_period=sync_period)
-        out, failed = [], 0.0
-        try:
-            runner.train_steps(warmup, eps)
-            runner.sync()
-        except Exception as e:  # noqa: BLE001
-            failed = 1.0; print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
-        for _ in range(reps):
-            barrier()
-            wall = dev_ms = 0.0; dec = 0
-            if not failed:
-                try:
-                    s0 = eng.stats()
-                    eng.timer_start()
-                    t0 = time.perf_counter()
-                    runner.train_steps(steps, eps)
-                    if final_exchange:
-                        runner.sync()
-                    dev_ms = eng.timer_stop()          # waits for the stream: this rank's K steps are done
-                    wall = time.perf_counter() - t0    # (MAX over ranks below = the job's time)
-                    runner.sync()
-                    eng.sync()
-                    dec = eng.stats()["decisions"] - s0["decisions"]
-                except Exception as e:  # noqa: BLE001
-                    failed = 1.0; print(f"bench.py rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
-            barrier()
-            if comm:
-                wall, failed = (float(x) for x in comm.all_reduce_max([wall, failed])); dec = int(comm.all_reduce_sum([float(dec)])[0])
-            out.append((wall, dec, dev_ms))
-        return None if failed else out
+        """dist.timed_region on this run's engine / communicator: W untimed + `reps` x exactly `steps` timed agent periods, barrier + device sync on
+        both sides of every repetition, MAX over ranks / SUM of env-steps; None when the device part failed on any rank (every rank still took part
+        in every collective)"""
+        return timed_region(eng, comm, reducer if red == "default" else red, sync_period, steps, warmup, args.eps if eps is None else eps, reps=reps,
+                            final_exchange=final_exchange, log=lambda m: print(f"bench.py rank {rank}: {m}", file=sys.stderr))
 
     def median_rep(rs):
-        """(wall, env_steps, device_ms) of the repetition with the median throughput + the spread over the repetitions"""
-        order = sorted(range(len(rs)), key=lambda i: rs[i][1] / rs[i][0])
-        m = rs[order[len(order) // 2]]
-        vals = [r[1] / r[0] for r in rs]
-        return m, {"n": len(rs), "value_min": min(vals), "value_max": max(vals), "ms_per_step_min": min(r[0] for r in rs) * 1e3 / args.steps,
-                   "ms_per_step_max": max(r[0] for r in rs) * 1e3 / args.steps, "statistic": "median over back-to-back repetitions of the K-step timed region"}
-
-    def tables_hash():
-        """6 x 32 bits of SHA-256 over the three tables (as exact float64 values for the max / min all-reduce)"""
-        qa, qb, cnt = eng.get_tables()
-        h = hashlib.sha256(qa.tobytes() + qb.tobytes() + cnt.tobytes()).digest()
-        return [float(int.from_bytes(h[4 * i:4 * i + 4], "little")) for i in range(6)]
-
-    def replicas_identical():
-        """after an exchange: do all ranks hold the same tables?  all-reduce(max) and all-reduce(min) of the table hash must agree"""
-        h = tables_hash()
-        if not comm or world == 1:
-            return True
-        hi = comm.all_reduce_max(h); lo = -comm.all_reduce_max([-x for x in h])
-        return bool((hi == lo).all())
+        return median_repetition(rs, args.steps)
 
     # pre-roll + W warm-up periods, all untimed, all on the run's own table schedule (exchanges included with several ranks)
     reps = timed(args.sync_period, args.steps, args.preroll + args.warmup, reps=max(1, args.repeats))
@@ -589,7 +540,7 @@ def main():
     (wall, decisions, dev_ms), spread = median_rep(reps)
     sync_info = None
     if multi:
-        identical = replicas_identical()   # the timed region ended on exchanged tables: every rank must hold the same three tables now
+        identical = replicas_identical(eng, comm)   # the timed region ended on exchanged tables: every rank must hold the same three tables now
         EXCHANGE_TEXT = {"p2p": "flush + push of 11 340 int64 words into every rank's exchange buffer (HIP IPC, uncached) + flags + local sum + fold, on the engine's stream",
                          "rccl": "flush + ncclAllReduce(ncclInt64, ncclSum, 11 340 words = 90 720 B) + fold, on the engine's stream"}
         # the exchange's price: same region without exchanges (one window, folded after the clock stops: NOT a valid training
@@ -624,7 +575,7 @@ def main():
                 sync_info[other] = {"skipped": "the exchange failed inside its timed leg (a peer was not seen within p2p_spin_limit polls); see stderr"}
             else:
                 (w_o, d_o, _), sp_o = median_rep(r_o)
-                ident_o = replicas_identical()
+                ident_o = replicas_identical(eng, comm)
                 ms_o, n_o = exchange_device_ms(reducers[other])
                 sync_info[other] = {"value": d_o / w_o, "ms_per_step": w_o * 1e3 / args.steps, "sync_ms_per_step": (w_o - w_none) * 1e3 / args.steps, "exchange_device_ms": ms_o,
                                     "exchanges_timed": n_o, "replicas_identical": ident_o, "value_min": sp_o["value_min"], "value_max": sp_o["value_max"], "exchange": EXCHANGE_TEXT[other]}

@@ -12,7 +12,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
 OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL, EPEER = 0, -1, -2, -3, -4, -5, -6
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 P2P_MAX_RANKS = 8
@@ -24,7 +24,7 @@ class DqlStatsC(C.Structure):
                 ("by_code", C.c_int64 * N_CHECK_CODES), ("reward_sum", C.c_double), ("physics_ticks", C.c_int64)]
 
 
-# every symbol include/dql.h declares: name -> (restype, argtypes)
+# every symbol include/dql.h and include/dql_diag.h (dql_diag_*: measurement and self-test, not part of the drop-in boundary) declare: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
 _cfgp = C.POINTER(DqlConfigC)
 SYMBOLS = {
@@ -61,7 +61,7 @@ SYMBOLS = {
     "dql_transfer": (C.c_int, [_vp, _i32, _dbl]),
     "dql_set_sync_period": (C.c_int, [_vp, _i32]),
     "dql_set_windowed": (C.c_int, [_vp, _i32]),
-    "dql_accum_dev_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "dql_diag_accum_dev_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "dql_set_window_buffer": (C.c_int, [_vp, _vp]),
     "dql_stream_handle": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dql_flush": (C.c_int, [_vp]),
@@ -88,14 +88,14 @@ SYMBOLS = {
     "dql_p2p_push_window": (C.c_int, [_vp]),
     "dql_p2p_wait_window": (C.c_int, [_vp]),
     "dql_p2p_status": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
-    "dql_sync_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    "dql_diag_sync_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
     "dql_stats_get": (C.c_int, [_vp, C.POINTER(DqlStatsC)]),
     "dql_stats_reset": (C.c_int, [_vp]),
-    "dql_timer_start": (C.c_int, [_vp]),
-    "dql_timer_stop": (C.c_int, [_vp, C.POINTER(_dbl)]),
-    "dql_kernel_timer": (C.c_int, [_vp, _i32]),
-    "dql_kernel_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
-    "dql_delay": (C.c_int, [_vp, _dbl]),
+    "dql_diag_timer_start": (C.c_int, [_vp]),
+    "dql_diag_timer_stop": (C.c_int, [_vp, C.POINTER(_dbl)]),
+    "dql_diag_kernel_timer": (C.c_int, [_vp, _i32]),
+    "dql_diag_kernel_time_ms": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    "dql_diag_delay": (C.c_int, [_vp, _dbl]),
     "dql_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "dql_episode_log_enable": (C.c_int, [_vp, _i32]),
     "dql_episode_log_read": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
@@ -109,7 +109,7 @@ SYMBOLS = {
     "dql_pid_run": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "dql_attitude_run": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _i64, _i32, _vp]),
     "dql_platform_run": (C.c_int, [_cfgp, C.c_int, _i64, _i32, _vp]),
-    "dql_selftest_sqrt": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_i64)]),
+    "dql_diag_selftest_sqrt": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_i64)]),
     "dql_place": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _i64, _vp]),
     "dql_agent_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "dql_agent_destroy": (C.c_int, [_vp]),

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "dql_device.hpp"
+#include "../../include/dql_diag.h"
 
 using namespace dql;
 
@@ -508,7 +509,7 @@ __global__ void k_mark_reset(int4* si, const uint8_t* mask, long long n) {
   v.w |= (FL_DONE << 8);
   si[i] = v;
 }
-// holds a stream for `ticks` of the 100 MHz wall clock (cohort phase offset, dql_delay): one wave, exits on time or on the iteration bound
+// holds a stream for `ticks` of the 100 MHz wall clock (cohort phase offset, dql_diag_delay): one wave, exits on time or on the iteration bound
 __global__ void k_delay(unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();
   for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
@@ -663,7 +664,7 @@ template <typename T> __global__ void k_platform_run(SimK<T> s, long long n, int
     out[i * 4] = (double)e.mp_x; out[i * 4 + 1] = (double)e.mp_y; out[i * 4 + 2] = (double)e.mp_u; out[i * 4 + 3] = (double)e.mp_v;
   }
 }
-// exhaustive self-test of sqrt_pos (dql_selftest_sqrt): inputs with bit patterns lo .. hi against (float)sqrt((double)x)
+// exhaustive self-test of sqrt_pos (dql_diag_selftest_sqrt): inputs with bit patterns lo .. hi against (float)sqrt((double)x)
 __global__ void k_selftest_sqrt(unsigned lo, unsigned hi, unsigned long long* bad) {
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long n = 0;
@@ -908,6 +909,12 @@ static int check_config(const dql_config* c) {
   if (c->manager_div > 255 || !(1.0 / (c->f_ag * c->dt) + 1.0 < 256.0)) return fail(DQL_EINVAL, "an agent period must hold fewer than 255 physics ticks (1 / (f_ag dt)) and manager_div must be <= 255");
   if (c->mass <= 0 || c->k_f <= 0 || c->k_m <= 0 || c->arm_length <= 0) return fail(DQL_EINVAL, "vehicle constants must be positive");
   if (c->init_uniform < 0 || c->init_uniform > 2) return fail(DQL_EINVAL, "init_uniform must be 0 (normal at level 0, else uniform), 1 (uniform) or 2 (SimulationLandingEnv placement)");
+  if (c->dtype == DQL_F32) {
+    // the float32 tick clamps the allocated w^2 at rotor_max^2 BEFORE the root (rotor_cmd: one med3 instead of a max before and a min after):
+    // min(sqrt(x), omax) == sqrt(min(x, omax^2)) bit for bit only when omax^2 is a float32 (the reference's 838^2 = 702 244 is)
+    const float om = (float)c->rotor_max; const double p2 = (double)om * (double)om;
+    if (!(c->rotor_max > 0) || (double)(float)p2 != p2) return fail(DQL_EINVAL, "float32 contexts need a rotor_max whose square is exactly representable in float32 (the reference's 838 is); use dtype float64 for this vehicle");
+  }
   // step_count and curriculum_check are packed into 16 bits each (store_env): an episode must time out before they wrap
   if (!(c->t_max > 0) || c->t_max * c->f_ag >= 65535.0) return fail(DQL_EINVAL, "t_max * f_ag must be in (0, 65535): the per-env step counters are 16 bits wide");
   return DQL_OK;
@@ -1019,7 +1026,7 @@ template <typename T> static void launch_step_b(dql_ctx* x, int mode, double eps
 static int launch_period(dql_ctx* x, int mode, double eps, int n_periods = 1) {
   if (x->elog && x->elog_n + n_periods > x->elog_cap) return fail(DQL_ESTATE, "episode log full: read it with dql_episode_log_read before stepping on");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (x->kernel_timer) {  // the pair belongs to the context from its creation on (dql_kernel_timer / dql_destroy free it), whatever fails below
+  if (x->kernel_timer) {  // the pair belongs to the context from its creation on (dql_diag_kernel_timer / dql_destroy free it), whatever fails below
     HIP_TRY(hipEventCreate(&e0)); x->kev.push_back(e0);
     if (hipEventCreate(&e1) != hipSuccess) { x->kev.pop_back(); (void)hipEventDestroy(e0); return fail(DQL_EHIP, "hipEventCreate failed"); }
     x->kev.push_back(e1);
@@ -1440,9 +1447,15 @@ int dql_get_sim_state(dql_ctx* x, double* out, int32_t cap) {
   if (!out || cap < NF_REAL) return fail(DQL_EINVAL, "out buffer must hold 64 fields x n_envs doubles");
   return x->dtype == DQL_F32 ? get_sim_state_t<float>(x, out) : get_sim_state_t<double>(x, out);
 }
+static int real_field_index(const char* name);  // (the name table sits further down, with dql_field_name)
 int dql_set_sim_state(dql_ctx* x, const double* in, int32_t nf) {
   CHECK_CTX(x);
   if (!in || nf != NF_REAL) return fail(DQL_EINVAL, "in buffer must hold exactly 64 fields x n_envs doubles");
+  if (x->dtype == DQL_F32 && !x->cfg.two_axis) {  // the x-axis float32 kernels fly attitude()'s closed form for roll_sp == 0 and never read the field
+    const int f_roll = real_field_index("roll_sp");
+    for (long long i = 0; f_roll >= 0 && i < x->n; ++i)
+      if (in[(long long)f_roll * x->n + i] != 0.0) return fail(DQL_EINVAL, "roll_sp must be 0 in an x-axis float32 context (its attitude law is the closed form for a zero roll set-point); use two_axis = 1 or dtype float64");
+  }
   return x->dtype == DQL_F32 ? set_sim_state_t<float>(x, in) : set_sim_state_t<double>(x, in);
 }
 int dql_get_sim_ints(dql_ctx* x, int32_t* out, int32_t cap) {
@@ -1487,6 +1500,10 @@ static const char* const k_real_names[NF_REAL] = {
     "shp_y_p", "shp_y_v", "shp_y_a", "cum_y", "mp_r", "mp_w", "pad0", "pad1",
     "reward", "obs_p_x", "obs_v_x", "obs_a_x", "obs_p_y", "obs_v_y", "obs_a_y", "pad2"};
 static const char* const k_int_names[NF_INT] = {"idx_x", "idx_y", "step_count", "cur_check", "code", "flags", "action"};
+static int real_field_index(const char* name) {
+  for (int f = 0; f < NF_REAL; ++f) if (!strcmp(k_real_names[f], name)) return f;
+  return -1;
+}
 int dql_n_fields(int32_t* n_real, int32_t* n_int) { if (n_real) *n_real = NF_REAL; if (n_int) *n_int = NF_INT; return DQL_OK; }
 const char* dql_field_name(int32_t i, int32_t is_int) {
   if (is_int) return (i >= 0 && i < NF_INT) ? k_int_names[i] : nullptr;
@@ -1566,7 +1583,7 @@ int dql_set_windowed(dql_ctx* x, int32_t on) {
   x->windowed = on != 0;
   return DQL_OK;
 }
-int dql_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
+int dql_diag_accum_dev_ptr(dql_ctx* x, void** dev_ptr, int64_t* n_int64) {
   CHECK_CTX(x);
   if (dev_ptr) *dev_ptr = x->window;
   if (n_int64) *n_int64 = DQL_ACC_LEN;
@@ -1662,14 +1679,14 @@ int dql_stats_reset(dql_ctx* x) {
   x->stats_step_base = x->step_index;
   return DQL_OK;
 }
-int dql_timer_start(dql_ctx* x) {
+int dql_diag_timer_start(dql_ctx* x) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   x->timer_launches = 0;
   HIP_TRY(hipEventRecord(x->ev0, x->stream));
   return DQL_OK;
 }
-int dql_timer_stop(dql_ctx* x, double* ms) {
+int dql_diag_timer_stop(dql_ctx* x, double* ms) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipEventRecord(x->ev1, x->stream));
@@ -1679,7 +1696,7 @@ int dql_timer_stop(dql_ctx* x, double* ms) {
   if (ms) *ms = (double)f;
   return DQL_OK;
 }
-int dql_kernel_timer(dql_ctx* x, int32_t on) {
+int dql_diag_kernel_timer(dql_ctx* x, int32_t on) {
   CHECK_CTX(x);
   for (hipEvent_t e : x->kev) (void)hipEventDestroy(e);
   x->kev.clear();
@@ -1688,7 +1705,7 @@ int dql_kernel_timer(dql_ctx* x, int32_t on) {
   x->kernel_timer = on != 0;
   return DQL_OK;
 }
-int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
+int dql_diag_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipStreamSynchronize(x->stream));
@@ -1698,7 +1715,7 @@ int dql_kernel_time_ms(dql_ctx* x, double* avg_ms, int64_t* launches) {
   if (launches) *launches = n;
   return DQL_OK;
 }
-int dql_delay(dql_ctx* x, double microseconds) {
+int dql_diag_delay(dql_ctx* x, double microseconds) {
   CHECK_CTX(x);
   if (!(microseconds >= 0.0) || microseconds > 1e5) return fail(DQL_EINVAL, "delay must be in 0 .. 100 000 us");
   HIP_TRY(hipSetDevice(x->device));
@@ -1706,7 +1723,7 @@ int dql_delay(dql_ctx* x, double microseconds) {
   HIP_TRY(hipGetLastError());
   return DQL_OK;
 }
-int dql_sync_time_ms(dql_ctx* x, double* avg_ms, int64_t* syncs) {
+int dql_diag_sync_time_ms(dql_ctx* x, double* avg_ms, int64_t* syncs) {
   CHECK_CTX(x);
   HIP_TRY(hipSetDevice(x->device));
   HIP_TRY(hipStreamSynchronize(x->stream));
@@ -1982,7 +1999,7 @@ int dql_platform_run(const dql_config* cfg, int device, int64_t n, int32_t carry
   return DQL_OK;
 }
 
-int dql_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded) {
+int dql_diag_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded) {
   if (!not_correctly_rounded) return fail(DQL_EINVAL, "null pointer");
   if (lo_bits > hi_bits || hi_bits > 0x7f7fffffu) return fail(DQL_EINVAL, "bit patterns must satisfy lo <= hi <= 0x7f7fffff (largest finite float32)");
   OP_PROLOGUE(device)

@@ -144,3 +144,113 @@ class ShardedGroup:
                 e.p2p_wait_window()
                 e.apply_accum()
         self._since = 0
+
+
+# ---- measuring and checking the exchange (bench.py; exercised at world size 2 on CPU by tests/test_dist_gloo.py) ----
+def tables_fingerprint(qa, qb, count):
+    """6 x 32 bits of SHA-256 over the three tables' bytes, as floats (every 32-bit integer is an exact float64): what ranks compare"""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256(np.ascontiguousarray(qa, dtype=np.float64).tobytes() + np.ascontiguousarray(qb, dtype=np.float64).tobytes()
+                       + np.ascontiguousarray(count, dtype=np.float64).tobytes()).digest()
+    return [float(int.from_bytes(h[4 * i:4 * i + 4], "little")) for i in range(6)]
+
+
+def replicas_identical(engine, comm) -> bool:
+    """After an exchange every rank must hold bit-identical tables: all-reduce(max) and all-reduce(min) of the tables' fingerprint agree.
+    (The one N > 1 correctness check a run can make about itself; `comm` = RcclComm or any object with all_reduce_max.)"""
+    import numpy as np
+    fp = tables_fingerprint(*engine.get_tables())
+    if comm is None or getattr(comm, "world", 1) == 1:
+        return True
+    hi = np.asarray(comm.all_reduce_max(fp)); lo = -np.asarray(comm.all_reduce_max([-x for x in fp]))
+    return bool((hi == lo).all())
+
+
+def timed_region(engine, comm, reducer, sync_period: int, steps: int, warmup: int, eps: float, reps: int = 1, final_exchange: bool = True, log=None):
+    """`warmup` untimed + `reps` x exactly `steps` timed agent periods on `engine` with table exchanges through `reducer` every `sync_period`
+    periods.  Every repetition is bracketed by barrier + device sync on both sides; per repetition the wall time is the MAX over ranks and the
+    env-steps the SUM.  A repetition ends on exchanged tables (a window still open after `steps` periods is exchanged inside the clock) unless
+    final_exchange is False (the no-exchange yardstick).  A rank on which the device part raises (a peer-to-peer exchange that gave up on a peer)
+    STILL takes part in every collective, and every rank then returns None — a failed leg never strands the others in an all-reduce.
+    Returns [(wall_s, env_steps, device_ms)] per repetition."""
+    import time
+    runner = ShardedRunner(engine, reducer, sync_period=sync_period)
+    has_timer = hasattr(engine, "timer_start")
+    multi = comm is not None and getattr(comm, "world", 1) > 1
+
+    def barrier():
+        engine.sync() if hasattr(engine, "sync") else None
+        if comm is not None:
+            comm.barrier()
+            engine.sync() if hasattr(engine, "sync") else None
+
+    out, failed = [], 0.0
+    try:
+        runner.train_steps(warmup, eps)
+        runner.sync()
+    except Exception as e:  # noqa: BLE001
+        failed = 1.0
+        if log:
+            log(f"{type(e).__name__}: {e}")
+    for _ in range(reps):
+        barrier()
+        wall, dev_ms, dec = 0.0, 0.0, 0
+        if not failed:
+            try:
+                d0 = engine.stats()["decisions"]
+                if has_timer:
+                    engine.timer_start()
+                t0 = time.perf_counter()
+                runner.train_steps(steps, eps)
+                if final_exchange:
+                    runner.sync()
+                if has_timer:
+                    dev_ms = engine.timer_stop()       # waits for the stream: this rank's K steps are done
+                wall = time.perf_counter() - t0        # (MAX over ranks below = the job's time)
+                runner.sync()
+                engine.sync() if hasattr(engine, "sync") else None
+                dec = engine.stats()["decisions"] - d0
+            except Exception as e:  # noqa: BLE001
+                failed = 1.0
+                if log:
+                    log(f"{type(e).__name__}: {e}")
+        barrier()
+        if multi:
+            wall, failed = (float(x) for x in comm.all_reduce_max([wall, failed]))
+            dec = int(comm.all_reduce_sum([float(dec)])[0])
+        out.append((wall, dec, dev_ms))
+    return None if failed else out
+
+
+def median_repetition(reps, steps: int):
+    """(wall_s, env_steps, device_ms) of the repetition with the median throughput, and the spread over the repetitions"""
+    order = sorted(range(len(reps)), key=lambda i: reps[i][1] / reps[i][0])
+    m = reps[order[len(order) // 2]]
+    vals = [r[1] / r[0] for r in reps]
+    return m, {"n": len(reps), "value_min": min(vals), "value_max": max(vals), "ms_per_step_min": min(r[0] for r in reps) * 1e3 / steps,
+               "ms_per_step_max": max(r[0] for r in reps) * 1e3 / steps, "statistic": "median over back-to-back repetitions of the K-step timed region"}
+
+
+def compare_exchanges(engine, comm, reducers: dict, primary: str, sync_period: int, steps: int, warmup: int, eps: float, reps: int = 3, log=None, skip_reasons=None):
+    """Times every exchange in `reducers` (name -> reducer) on the SAME engine and schedule, in one run, and checks after each leg that the replicas are
+    identical.  Returns {name: {"value", "ms_per_step", "replicas_identical", ...} | {"skipped": reason}}; the primary one first (its figures are the run's).
+    A leg that fails is reported as skipped, the others still run — but nothing runs after a failed leg on the same engine (its tables may have diverged)."""
+    out = {}
+    order = [primary] + [k for k in reducers if k != primary]
+    broken = None
+    for name in order:
+        if name not in reducers:
+            out[name] = {"skipped": (skip_reasons or {}).get(name, "not set up")}
+            continue
+        if broken:
+            out[name] = {"skipped": f"not run: the {broken} leg failed before it on this engine"}
+            continue
+        r = timed_region(engine, comm, reducers[name], sync_period, steps, warmup if name != primary else 0, eps, reps=reps, log=log)
+        if r is None:
+            out[name] = {"skipped": "the exchange failed inside its timed leg (see stderr)"}
+            broken = name
+            continue
+        (w, d, _), spread = median_repetition(r, steps)
+        out[name] = {"value": d / w, "ms_per_step": w * 1e3 / steps, "replicas_identical": replicas_identical(engine, comm), "value_min": spread["value_min"], "value_max": spread["value_max"]}
+    return out

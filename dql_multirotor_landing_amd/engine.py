@@ -176,7 +176,7 @@ class Engine:
 
     def accum_dev_ptr(self):
         p = C.c_void_p(); n = C.c_int64()
-        _lib.check(self.lib.dql_accum_dev_ptr(self._h, C.byref(p), C.byref(n)))
+        _lib.check(self.lib.dql_diag_accum_dev_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
     def set_window_buffer(self, dev_ptr):
@@ -248,7 +248,7 @@ class Engine:
 
     def sync_time_ms(self):
         ms = C.c_double(); n = C.c_int64()
-        _lib.check(self.lib.dql_sync_time_ms(self._h, C.byref(ms), C.byref(n)))
+        _lib.check(self.lib.dql_diag_sync_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     # ---- checkpoint / resume ----
@@ -275,23 +275,23 @@ class Engine:
         _lib.check(self.lib.dql_stats_reset(self._h))
 
     def timer_start(self):
-        _lib.check(self.lib.dql_timer_start(self._h))
+        _lib.check(self.lib.dql_diag_timer_start(self._h))
 
     def timer_stop(self) -> float:
         ms = C.c_double()
-        _lib.check(self.lib.dql_timer_stop(self._h, C.byref(ms)))
+        _lib.check(self.lib.dql_diag_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
     def kernel_timer(self, on: bool):
-        _lib.check(self.lib.dql_kernel_timer(self._h, int(on)))
+        _lib.check(self.lib.dql_diag_kernel_timer(self._h, int(on)))
 
     def kernel_time_ms(self):
         ms = C.c_double(); n = C.c_int64()
-        _lib.check(self.lib.dql_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
+        _lib.check(self.lib.dql_diag_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def delay(self, microseconds: float):
-        _lib.check(self.lib.dql_delay(self._h, float(microseconds)))
+        _lib.check(self.lib.dql_diag_delay(self._h, float(microseconds)))
 
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.dql_set_option(self._h, name.encode(), int(value)))

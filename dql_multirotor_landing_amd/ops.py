@@ -131,7 +131,7 @@ def selftest_sqrt(lo: float = 1e-30, hi: float = 3.4028234663852886e38, device: 
     """number of float32 inputs in [lo, hi] for which the float32 tick's square root is not the correctly rounded one (must be 0)"""
     lo_b = int(np.float32(lo).view(np.uint32)); hi_b = int(np.float32(hi).view(np.uint32))
     n = C.c_int64(-1)
-    _lib.check(_lib.load().dql_selftest_sqrt(device, lo_b, hi_b, C.byref(n)))
+    _lib.check(_lib.load().dql_diag_selftest_sqrt(device, lo_b, hi_b, C.byref(n)))
     return n.value
 
 

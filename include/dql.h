@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DQL_ABI_VERSION 4
+#define DQL_ABI_VERSION 5 /* 5: tick replay operators (dql_*_run), measurement symbols moved to dql_diag.h as dql_diag_* */
 
 typedef enum dql_status {
   DQL_OK = 0,
@@ -191,7 +191,16 @@ int dql_get_states(dql_ctx* ctx, int32_t* idx_x, int32_t* idx_y_or_null); /* pac
 int dql_get_rewards(dql_ctx* ctx, double* rewards);
 int dql_get_dones(dql_ctx* ctx, uint8_t* dones, int8_t* codes_or_null);
 int dql_get_actions(dql_ctx* ctx, uint8_t* actions);
-/* raw continuous state, field-major [n_fields][n_envs] as doubles (see dql_field_names) */
+/* raw continuous state, field-major [n_fields][n_envs] as doubles (see dql_field_names).
+ * All 64 real fields mean the same in float32 and float64 contexts EXCEPT the two PIDs' Butterworth filter fields vz_x1 vz_x2 vz_y1 vz_y2 vz_y3 and
+ * yw_*: a float64 context keeps the reference's histories there (x1, x2 = the last two inputs, y1..y3 = the last three outputs, pkg/filters.py:98-109),
+ * a float32 context the three states of the same recurrence in transposed form in (x1, x2, y1) with y2 = y3 = 0:
+ *   t1 = 2b x1 + b x2 - a2 y2 - a3 y3,  t2 = b x1 - a2 y1 - a3 y2,  t3 = -a3 y1   (b, a2, a3: csrc/dql_device.hpp butterworth).
+ * State written by one dtype must be mapped before it is handed to the other (host: dql_multirotor_landing_amd/state_layout.py; float64 -> float32
+ * only: three numbers do not determine five).  The library cannot tell the two apart: dql_set_sim_state trusts the caller.  The Trainer's
+ * checkpoints carry dtype + layout version and map or refuse a shard by themselves.
+ * A float32 x-axis context (two_axis = 0) flies the attitude law's closed form for a roll set-point of exactly 0: dql_set_sim_state refuses
+ * (DQL_EINVAL) a non-zero roll_sp field there instead of ignoring it. */
 int dql_get_sim_state(dql_ctx* ctx, double* out, int32_t n_fields_capacity);
 int dql_set_sim_state(dql_ctx* ctx, const double* in, int32_t n_fields);
 int dql_get_sim_ints(dql_ctx* ctx, int32_t* out, int32_t n_fields_capacity);
@@ -212,7 +221,6 @@ int dql_set_sync_period(dql_ctx* ctx, int32_t k_steps); /* 1 = apply every step 
 /* windowed accumulation: every step also adds its accumulators into the window buffer and updates only the local
  * work tables; dql_apply_accum folds the (all-reduced) window into the base tables and re-bases the work tables */
 int dql_set_windowed(dql_ctx* ctx, int32_t on);
-int dql_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64); /* device buffer to all-reduce (sum) */
 /* use a caller-owned device buffer of 4*2835 int64 as the window (e.g. a torch tensor handed to torch.distributed);
  * NULL restores the context's own buffer.  The buffer is zeroed; the context never frees it. */
 int dql_set_window_buffer(dql_ctx* ctx, void* dev_ptr);
@@ -285,19 +293,10 @@ int dql_p2p_exchange_window(dql_ctx* ctx);
 int dql_p2p_push_window(dql_ctx* ctx);
 int dql_p2p_wait_window(dql_ctx* ctx);
 int dql_p2p_status(dql_ctx* ctx, int32_t* failed_seq);
-/* average device time of the exchanges (all-reduce + fold) made while the kernel timer was armed (dql_kernel_timer) */
-int dql_sync_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* syncs);
 
-/* ---- stats / timing ---- */
+/* ---- stats ----  (timers, the kernel's self-test and other measurement equipment: include/dql_diag.h) */
 int dql_stats_get(dql_ctx* ctx, dql_stats* out);
 int dql_stats_reset(dql_ctx* ctx);
-int dql_timer_start(dql_ctx* ctx); /* hipEventRecord on the ctx stream */
-int dql_timer_stop(dql_ctx* ctx, double* elapsed_ms); /* records, synchronises, returns elapsed */
-/* average device duration of the fused step kernel over the launches made while the kernel timer was armed */
-int dql_kernel_time_ms(dql_ctx* ctx, double* avg_ms, int64_t* launches);
-int dql_kernel_timer(dql_ctx* ctx, int32_t on); /* arm / disarm per-launch event pairs around the fused step kernel */
-/* holds the context's stream for this long (a one-wave timer kernel): phase offset between contexts that share a GPU */
-int dql_delay(dql_ctx* ctx, double microseconds);
 /* knobs: "block" (0 = auto, 64, 128, 256 threads per workgroup; 512 = float32 at 4 waves per SIMD); "tick" (0 = auto; layout of the
  * 500 Hz loop: 1 plain loop on scalar-register constants, 2 constants in vector registers + loop laid out per manager period, 3 the
  * packed float32 tick, 4 constants as instruction literals — float32 contexts whose vehicle / controller constants are the
@@ -376,10 +375,6 @@ int dql_attitude_run(const dql_config* cfg, int device, const double* quat_xyzw,
  * (float32 only): sine / cosine evaluated at every carry-th tick and rotated through the constant phase step in between, as the fused float32
  * step carries them through the four or five manager ticks of an agent period */
 int dql_platform_run(const dql_config* cfg, int device, int64_t n, int32_t carry, double* out);
-/* Self-test of the float32 tick's square root (csrc/dql_device.hpp sqrt_pos: v_rsq_f32 + Goldschmidt step + residual correction): counts the
- * inputs with bit patterns lo_bits .. hi_bits whose result is NOT the correctly rounded sqrt.  The CPU oracle computes sqrtf(); parity is
- * bit for bit only while this count is 0 on the tick's domain [1e-30, FLT_MAX] — all 2.1e9 inputs take under a second. */
-int dql_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded);
 /* start coordinate of the drone along one axis for n (random offset x0, platform coordinate) pairs: the placement arithmetic of
  * TrainingLandingEnv.reset / SimulationLandingEnv.reset selected by cfg->init_uniform (see dql_config) */
 int dql_place(const dql_config* cfg, int device, const double* x0, const double* mp, int64_t n, double* out);

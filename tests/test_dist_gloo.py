@@ -317,3 +317,73 @@ def test_resume_with_a_mismatching_shard_stops_every_rank_after_the_vote(tmp_pat
     # (d) all good on both ranks: the state is restored
     tr._comm = FakeComm([0.0, 0.0])
     assert tr._restore_env_state(eng, progress) is True
+
+
+# ---- round 5: the first multi-GPU run must answer every open question by itself: both exchanges timed in ONE run,
+# a hash of the three tables compared across ranks after the final exchange, and a failing exchange must not strand the other ranks ----
+def _exchange_worker(rank, world, port, out_dir, case):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import json
+    import torch.distributed as dist
+    from _torch_comm import HostWindowReducer, TorchComm
+    from dql_multirotor_landing_amd.config import DqlConfig, F64
+    from dql_multirotor_landing_amd.dist import compare_exchanges, replicas_identical, shard_range, timed_region
+    OracleEngine = _oracle_engine_class()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = TorchComm()
+    lo, hi = shard_range(N_TOTAL, rank, world)
+    eng = OracleEngine(DqlConfig(dtype=F64), hi - lo, seed=42, env_id_offset=lo)
+    eng.sync = lambda: None
+    res = {}
+
+    class Failing:   # a peer-to-peer exchange that gives up on a peer.  Like the real one it involves NO host collective (every rank's device-side wait is
+        calls = 0    # bounded by itself), so a rank that fails leaves nobody waiting inside the exchange; the failure surfaces on ONE rank only
+        def __init__(self, engine):
+            self.engine = engine
+        def all_reduce(self):
+            Failing.calls += 1
+            self.engine.flush()
+            if rank == 1 and Failing.calls > 2:
+                raise RuntimeError("peer-to-peer table exchange gave up waiting for a peer")
+
+    if case == "both":
+        res["legs"] = compare_exchanges(eng, comm, {"rccl": HostWindowReducer(eng), "p2p": HostWindowReducer(eng)}, "rccl", sync_period=4, steps=12, warmup=4, eps=0.5, reps=3)
+        res["identical_after"] = replicas_identical(eng, comm)
+        if rank == 1:   # one rank's replica drifts (what a half-applied exchange would leave behind): the check must see it on EVERY rank
+            eng.o._qa[7] += 1e-9
+        res["identical_after_drift"] = replicas_identical(eng, comm)
+    elif case == "failing":
+        res["legs"] = compare_exchanges(eng, comm, {"rccl": HostWindowReducer(eng), "p2p": Failing(eng)}, "rccl", sync_period=4, steps=12, warmup=4, eps=0.5, reps=3,
+                                        log=lambda m: None)
+        res["after"] = timed_region(eng, comm, HostWindowReducer(eng), 4, 8, 0, 0.5, reps=1) is not None   # the communicator is still usable: nobody hangs
+    (Path(out_dir) / f"ex{rank}.json").write_text(json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["both", "failing"])
+def test_both_exchanges_in_one_run_and_replica_check(tmp_path, case):
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_exchange_worker, args=(2, _free_port(), str(tmp_path), case), nprocs=2, join=True)
+    r0, r1 = (json.loads((tmp_path / f"ex{r}.json").read_text()) for r in range(2))
+    if case == "both":
+        for r in (r0, r1):
+            assert list(r["legs"]) == ["rccl", "p2p"]                                    # the primary exchange first, then the other, same engine
+            for leg in r["legs"].values():
+                assert leg["replicas_identical"] is True and leg["value"] > 0 and leg["value_min"] <= leg["value"] <= leg["value_max"]
+            assert r["identical_after"] is True and r["identical_after_drift"] is False   # a 1e-9 drift in ONE cell of ONE rank is seen by both
+        assert r0["legs"]["rccl"]["value"] == r1["legs"]["rccl"]["value"]                 # MAX over ranks / SUM of env-steps: one figure for the job
+    else:
+        for r in (r0, r1):
+            assert r["legs"]["rccl"]["replicas_identical"] is True
+            assert "skipped" in r["legs"]["p2p"] and "failed" in r["legs"]["p2p"]["skipped"]   # on BOTH ranks, although only rank 1 raised
+            assert r["after"] is True
+
+
+def test_tables_fingerprint_is_exact_in_float64():
+    from dql_multirotor_landing_amd.dist import tables_fingerprint
+    a = np.arange(2835.0); b = a.copy(); b[100] = np.nextafter(b[100], 1e9)
+    f1, f2 = tables_fingerprint(a, a, a), tables_fingerprint(a, b, a)
+    assert f1 != f2 and all(float(int(x)) == x and 0 <= x < 2 ** 32 for x in f1 + f2)
+    assert tables_fingerprint(a.reshape(5, 567), a, a) == f1   # bytes, not shapes

@@ -815,3 +815,24 @@ def test_periods_per_launch_bit_exact(mods, P, n, block, kw):
     _compare(eng, orc, exact=True, what="windowed")
     with pytest.raises(ValueError):
         eng.set_option("periods_per_launch", 17)
+
+
+def test_float32_preconditions_are_checked_not_assumed(mods):
+    """(a) the float32 tick clamps w^2 at rotor_max^2 before the root — exact only when that square is a float32, so a vehicle for which it
+    is not is refused in float32 (and flies in float64); (b) an x-axis float32 context flies the attitude law's closed form for roll_sp == 0 and
+    never reads the field: a non-zero roll_sp handed to it is refused instead of ignored (a two-axis or float64 context takes it)."""
+    Engine, Oracle = mods
+    with pytest.raises(ValueError, match="rotor_max"):
+        Engine(DqlConfig(dtype=F32, rotor_max=800.1), 64)
+    Engine(DqlConfig(dtype=F32, rotor_max=838.5), 64).close()    # 838.5^2 = 703 082.25 is a float32
+    Engine(DqlConfig(dtype=F64, rotor_max=800.1), 64).close()
+    for kw, ok in ((dict(dtype=F32), False), (dict(dtype=F32, two_axis=1), True), (dict(dtype=F64), True)):
+        e = Engine(DqlConfig(**kw), 64, seed=1)
+        reals, ints = e.get_fields()
+        reals[e.field_names().index("roll_sp"), 5] = 0.05
+        if ok:
+            e.set_fields(reals, ints)
+        else:
+            with pytest.raises(ValueError, match="roll_sp"):
+                e.set_fields(reals, ints)
+        e.close()
