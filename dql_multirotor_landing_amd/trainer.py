@@ -88,7 +88,7 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
                "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after",
-               "population_gate", "env_kw")
+               "population_gate", "env_kw", "restart_after", "transfer_counts")
 
 
 class Trainer:
@@ -102,7 +102,7 @@ class Trainer:
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
                  periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, population_gate: Optional[float] = None,
-                 env_kw: Optional[Dict[str, Any]] = None, comm=None, reducer_factory=None) -> None:
+                 env_kw: Optional[Dict[str, Any]] = None, restart_after: Optional[float] = None, transfer_counts: float = 0.0, comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -151,6 +151,18 @@ class Trainer:
         # env_kw: DqlConfig fields of the simulated world beyond the Trainer's own arguments, e.g. config.AS_LAUNCHED (the parameters the
         # reference's manager node resolved under roslaunch: platform 1 m/s, observation noise 0.25 m / 0.1 m/s — tests/test_g14_gazebo.py)
         self._env_kw = dict(env_kw or {})
+        # restart_after (episodes per env; None = never, the reference's behaviour): a level k >= 1 that has not been promoted after this many episodes
+        # per env since its (re)start is started over — its slice of the tables is transferred from level k - 1 again (Eq. 31) and its visit counters
+        # cleared, the deque and the population window emptied.  Why: with zero exploration above level 0 (pkg/trainer.py:112-114) and learning rates
+        # at their floor, a level whose first few thousand greedy episodes settled on a slightly worse limit cycle STAYS there: 4 of 12 seeds sat at
+        # 0.89-0.93 population success for their whole 768-episodes-per-env budget in round 4 while the other levels promoted within 4-80 episodes per
+        # env (profiles/r4_bench_default_detail.json).  A restart is a fresh draw of that early phase; the promotion rule itself is untouched.
+        self._restart_after = None if restart_after is None else float(restart_after)
+        # (exploration above level 0 — eps 0.02 / 0.05 / 0.1 for a level's first 32 / 64 episodes per env — was tried and ends learning: no level above 0
+        # promoted in 4 of 4 seeds, profiles/r5_curriculum_upper_level_exploration.jsonl; the reference's "no exploration above level 0" stands)
+        # transfer_counts f (default 0 = the reference: a new level's visit counters start at 0, so its first visits learn with alpha = 1, 0.70, 0.57 ...):
+        # level k starts with count[k] = f * count[k - 1] — the transferred values are refined with the learning rates they were learnt with
+        self._transfer_counts = float(transfer_counts)
         if not 1 <= self._periods_per_launch <= 16 or self._chunk_steps % self._periods_per_launch:
             raise ValueError("periods_per_launch must be in 1..16 and divide chunk_steps")
         # device None: GPU LOCAL_RANK of a multi-rank launch (one process per GPU), GPU 0 of a single process; an explicit device wins
@@ -345,6 +357,13 @@ class Trainer:
             eng.set_option("periods_per_launch", self._periods_per_launch)
         return eng, ShardedRunner(eng, None)
 
+    def _seed_level_counts(self, eng, k):
+        _, _, cnt = eng.get_tables()
+        cnt = np.asarray(cnt, dtype=np.float64).reshape(-1).copy()
+        per_level = cnt.size // 5
+        cnt[k * per_level:(k + 1) * per_level] = np.floor(self._transfer_counts * cnt[(k - 1) * per_level:k * per_level])
+        eng.set_tables(count=cnt)
+
     def _chunk_counters(self, s, s_prev):
         by, by0 = s["by_code"], s_prev["by_code"]
         v = np.array([s["episodes"] - s_prev["episodes"], by["TERMINAL_SUCCESS"] - by0["TERMINAL_SUCCESS"],  # "Goal state reached" only (B17)
@@ -474,6 +493,8 @@ class Trainer:
             else:
                 if self._mode == "paper" and k >= 1:
                     eng.transfer(k, self.transfer_learning_ratio(k))  # Eq. 31 as intended: the new level starts from the previous one
+                    if self._transfer_counts > 0.0:
+                        self._seed_level_counts(eng, k)
                 eng.set_curriculum(k)  # "Create a new environment to update limits" (:175-183)
                 window = deque()  # aggregate rule: (episodes, goal-state successes) per chunk, trimmed to the most recent >= 100 episodes
                 pw.reset(); order.reset()
@@ -484,6 +505,8 @@ class Trainer:
             t_level = time.perf_counter()
             promoted = False
             promoted_at = None
+            restarts, restart_base = (int(pr.get("restarts", 0)), int(pr.get("restart_base", 0))) if resumed else (0, 0)
+            best_attempt = None  # (population success rate, tables) of the best attempt given up so far (not checkpointed: a resumed run starts collecting again)
             info: Dict[str, Any] = {}
             while episodes < self._max_num_episodes:
                 sched_episode = int(episodes / self._eps_episode_scale)
@@ -522,9 +545,24 @@ class Trainer:
                 done_level = (hit is not None) if ordered else (rate > self._success_rate)
                 if done_level and self._population_gate is not None and rate < self._population_gate:
                     done_level = False  # the judged envs' window passed, the population has not arrived: the level goes on (the deque keeps sliding)
+                if (not done_level and self._restart_after is not None and k >= 1 and self._mode == "paper"
+                        and episodes - restart_base >= self._restart_after * self._n_envs and episodes < self._max_num_episodes):
+                    # start the level over (see __init__): every rank does the same, at a chunk boundary = on synchronised tables
+                    qa_, qb_, cnt = (np.asarray(t, dtype=np.float64).reshape(-1).copy() for t in eng.get_tables())
+                    if best_attempt is None or rate > best_attempt[0]:  # the attempt given up may still be the best one the budget buys
+                        best_attempt = (rate, qa_, qb_, cnt.copy())
+                    per_level = cnt.size // 5
+                    cnt[k * per_level:(k + 1) * per_level] = np.floor(self._transfer_counts * cnt[(k - 1) * per_level:k * per_level]) if self._transfer_counts > 0.0 else 0.0
+                    eng.set_tables(count=cnt)
+                    eng.transfer(k, self.transfer_learning_ratio(k))
+                    window.clear(); pw.reset(); order.reset()
+                    if ordered:
+                        read_log()  # episodes already logged belong to the attempt that was given up
+                    cnt_prev = cnt
+                    restarts += 1; restart_base = episodes
                 if chunk_i % self._checkpoint_every == 0 and not done_level:
                     self._progress = {"level": k, "episodes": episodes, "steps": steps, "chunk_i": chunk_i, "window": [list(w) for w in window],
-                                      "pw": pw.get_state(), "order": order.get_state()}
+                                      "pw": pw.get_state(), "order": order.get_state(), "restarts": restarts, "restart_base": restart_base}
                     self.save()
                 self.log(info)
                 if done_level:
@@ -536,7 +574,12 @@ class Trainer:
                 if self._max_steps_per_level is not None and steps >= self._max_steps_per_level:
                     break
             exhausted = not promoted and episodes >= self._max_num_episodes
-            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "episodes": episodes,
+            if exhausted and best_attempt is not None and best_attempt[0] > (info.get("Success rate") or 0.0):
+                # the budget ran out in a later, worse attempt: the level hands over the tables of its best one (same rule as the reference's budget
+                # hand-over, pkg/trainer.py:187 — it just does not hand over a restart that had barely begun)
+                eng.set_tables(best_attempt[1], best_attempt[2], best_attempt[3])
+                info["Success rate"] = best_attempt[0]
+            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "restarts": restarts, "episodes": episodes,
                                  "agent_periods": steps, "success_rate": info.get("Success rate"),
                                  "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start})
             if self._mode == "reference":

@@ -387,3 +387,23 @@ def test_tables_fingerprint_is_exact_in_float64():
     f1, f2 = tables_fingerprint(a, a, a), tables_fingerprint(a, b, a)
     assert f1 != f2 and all(float(int(x)) == x and 0 <= x < 2 ** 32 for x in f1 + f2)
     assert tables_fingerprint(a.reshape(5, 567), a, a) == f1   # bytes, not shapes
+
+
+def test_level_restart_on_plateau(tmp_path, monkeypatch):
+    """Round 5, Trainer(restart_after=...): a level k >= 1 that has not been promoted after that many episodes per env is started over — its slice
+    transferred from level k - 1 again, its visit counters cleared, the promotion windows emptied; when the budget runs out the level hands over
+    the tables of its BEST attempt.  The promotion rule itself is untouched (an unreachable success rate never promotes); None = the reference."""
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    kw = dict(curriculum_steps=2, n_envs=48, chunk_steps=8, checkpoint_every=10**9, max_num_episodes=400, t_max=3, mode="paper", judge_envs=16,
+              successive_successful_episodes=10, eps_floor=0.3)
+    a = T.Trainer(save_path=tmp_path / "a", success_rate=2.0, restart_after=1.5, **kw)
+    ha = a.curriculum_training()
+    assert [h["promoted"] for h in ha] == [False, False] and ha[0]["restarts"] == 0 and ha[1]["restarts"] >= 3   # level 0 has nothing to restart from
+    b = T.Trainer(save_path=tmp_path / "b", success_rate=2.0, **kw)
+    hb = b.curriculum_training()
+    assert [h["restarts"] for h in hb] == [0, 0]
+    qa_a, _, cnt_a = a._engine.get_tables(); qa_b, _, cnt_b = b._engine.get_tables()
+    assert np.isfinite(qa_a).all() and not np.array_equal(qa_a, qb_ := qa_b)                 # the restarts changed the course of level 1
+    np.testing.assert_array_equal(np.asarray(qa_a).reshape(5, -1)[2:], 0.0)                  # and touched no level above it
+    assert np.asarray(cnt_a).reshape(5, -1)[1].sum() < np.asarray(cnt_b).reshape(5, -1)[1].sum()   # counters of the level were cleared on the way
