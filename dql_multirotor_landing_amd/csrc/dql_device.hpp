@@ -1416,7 +1416,7 @@ template <int TICK, typename T> struct TickConsts {
 enum { X_TWO = 0, X_ONLY = 1, X_RUNTIME = 2 };
 template <int TICK, int XMODE, typename T, typename TabPtr>
 DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, const MdpRun<T>& mr, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr,
-                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long mgr0, int sched) {
+                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long mgr0, int sched, unsigned prio_role = 0u) {
   DQL_SECTION("period_begin");
   const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps_thr, ext_action, seed, env_id, step_index);
   T B[9];
@@ -1441,6 +1441,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
   auto manager_tick = [&]() {
     DQL_SECTION("manager");
     DQL_PHASE(e, 2);
+#ifdef DQL_PRIO_TIME  // A/B: issue priority by wall-clock slice instead of by period (k_step)
+    { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();
+      if ((((unsigned)(t_ >> DQL_PRIO_TIME)) ^ prio_role) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0"); }
+#endif
+#ifdef DQL_PRIO_MGR   // A/B: by manager-tick parity
+    if ((((unsigned)mgr_index) ^ prio_role) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
+#endif
     manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
     manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec);
     ++mgr_in_step; ++mgr_index;

@@ -259,6 +259,7 @@ template <typename T> struct StepArgs {
   unsigned int eps_thr, pad_;  // explore <=> (r >> 8) < eps_thr: ceil(eps 2^24), the integer form of u24(r) < eps (host: eps_threshold)
   int sched[DQL_MAX_PERIODS];
   int mode, n_periods, env_blocks, have_prev, windowed;
+  int fair_prio;  // more env waves than SIMDs: the waves of a SIMD take turns at the issue priority (k_step)
 };
 
 // wave64 sum on the DPP path (no LDS permutes, no waits): row_shr 1, 2, 4, 8 build the prefix sums of each row of 16 lanes,
@@ -378,7 +379,30 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
   if constexpr (sizeof(T) == 4 && BLOCK < 512) cfgk = period_consts_in_vgprs(cfgk);
 #endif
   const TickConsts<TICK, T> tc(cfgk);
+#ifndef DQL_AB_NO_FAIR_PRIO
+  // ROUND 5: the two waves of a SIMD take turns at the issue priority.  The arbiter serves priority first, then AGE: of two waves running the same
+  // program the older one is nearly unimpeded and the younger gets the leftover slots — at exactly two waves per SIMD the older half of the env
+  // waves finished a 16-period launch after 272 us and the younger half then ran ALONE, at a lone wave's issue rate, for another 55 us
+  // (profiles/r5_wave_tail.jsonl).  Alternating s_setprio by (period + hardware wave slot) parity gives each wave the head of the queue in every
+  // other period: both finish together and the SIMD never runs half empty.  (A wave that shares its SIMD with nobody is unaffected.)
+  // compiled into the layouts that serve several waves per SIMD only (the packed / VGPR-constant layouts fly batches of at most one env wave per SIMD:
+  // nobody to take turns with, and the extra code cost them 0.8 %), and switched on by the host when the batch has more env waves than the device SIMDs
+  constexpr bool FAIR = (TICK == TICK_PLAIN || TICK == TICK_LIT) && BLOCK >= 128;
+  unsigned prio_role = 0u;
+  bool fair_prio = false;
+  if constexpr (FAIR) {
+    fair_prio = a.fair_prio != 0;
+    if (fair_prio) {
+      unsigned hw_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      prio_role = hw_id & 1u;  // wave slot parity: the two waves of a SIMD sit in slots 0 and 1
+    }
+  }
+#endif
   for (int p = 0; p < a.n_periods; ++p) {
+#if !defined(DQL_AB_NO_FAIR_PRIO) && !defined(DQL_PRIO_TIME) && !defined(DQL_PRIO_MGR)
+    if (fair_prio) { if ((((unsigned)p) ^ prio_role) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0"); }
+#endif
     dec = 0; don = 0; rfx = 0; goal = false;
     int done_code = -1;
     if (i < a.n) {
@@ -387,7 +411,13 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
         const int ax = ext & 3, ay = (ext >> 2) & 3;
         if (ax > 2 || ay > 2 || (ext >> 4) || (!a.c.two_axis && ay != 0 && ay != 2)) atomicAdd(&a.stats->bad_actions, 1ull);
       }
-      const StepOut o = agent_period<TICK, XMODE>(cfgk, tc, a.mdp, a.mdp_run, e, qx, a.qa, a.qb, a.mode, a.eps_thr, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.mgr0[p], a.sched[p]);
+      const StepOut o = agent_period<TICK, XMODE>(cfgk, tc, a.mdp, a.mdp_run, e, qx, a.qa, a.qb, a.mode, a.eps_thr, ext, a.seed, (uint32_t)(a.env_id_offset + i), a.step_index + p, a.mgr0[p], a.sched[p],
+#ifndef DQL_AB_NO_FAIR_PRIO
+                                                          prio_role
+#else
+                                                          0u
+#endif
+                                                          );
       DQL_SECTION("accumulate");
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
@@ -855,6 +885,7 @@ struct dql_ctx {
   bool pending = false;          // acc[(launch_index + 1) & 1] holds the last launch's accumulators, not yet folded into the master tables
   uint8_t* d_actions = nullptr;
   void* mdpk = nullptr;  // MdpK<T> in device memory
+  long long n_simds = 1024;         // SIMDs of the device (4 per compute unit): create_impl
   KalFix kal_fix{0.0, 0.0, false};  // fixed point of the Kalman covariance in this context's dtype (create_impl)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -974,6 +1005,7 @@ template <typename T> static StepArgs<T> make_step_args(dql_ctx* x, int mode, do
   }
   a.seed = x->seed; a.eps_thr = eps_threshold(eps); a.pad_ = 0; a.mode = mode; a.n_periods = n_periods;
   a.env_blocks = (int)((x->n + envs_per_block - 1) / envs_per_block); a.have_prev = x->pending ? 1 : 0; a.windowed = x->windowed ? 1 : 0;
+  a.fair_prio = ((x->n + 63) / 64 > x->n_simds) ? 1 : 0;
   return a;
 }
 template <typename T, int BLOCK, int TICK> static void launch_step_t(dql_ctx* x, int mode, double eps, int n_periods) {
@@ -1150,6 +1182,7 @@ static int create_impl(dql_ctx* x, const dql_config* cfg) {
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) return fail(DQL_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } while (0)
   HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&x->ev0)); HIP_TRY(hipEventCreate(&x->ev1));
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, x->device) == hipSuccess && cus > 0) x->n_simds = 4ll * cus; }
   if (cfg->dtype == DQL_F32) { const SimK<float> k = make_simk<float>(*cfg); x->kal_fix = KalFix{(double)k.kal_pss, (double)k.kal_kss, true}; }
   else { const SimK<double> k = make_simk<double>(*cfg); x->kal_fix = KalFix{k.kal_pss, k.kal_kss, true}; }
   x->lit_ok = cfg->dtype == DQL_F32 && refk_matches(make_simk<float>(*cfg, &x->kal_fix)) && refm_matches(make_mdpk<float>(*cfg));
