@@ -30,3 +30,10 @@ print(json.dumps({"envs": n, "periods_per_launch": P, "us_per_launch": ms * 1e3 
 hist, edges = np.histogram((t1[5] - t0[5].min()) / 100.0, bins=24)
 print(json.dumps({"end_time_histogram_us": [round(float(x), 1) for x in edges], "waves": hist.tolist()}))
 e.close()
+# by presumed XCD (workgroup index mod 8: the dispatcher deals workgroups round-robin over the 8 XCDs) and by presumed CU slot
+e2 = None
+f5 = (t1[5] - t0[5].min()) / 100.0
+wg = np.arange(f5.size) // (4 if n > 8192 else 1)
+print(json.dumps({"end_time_by_workgroup_mod_8_us": [round(float(f5[wg % 8 == k].mean()), 1) for k in range(8)],
+                  "end_time_by_workgroup_mod_8_p99_us": [round(float(np.percentile(f5[wg % 8 == k], 99)), 1) for k in range(8)],
+                  "end_time_first_vs_second_half_of_the_grid_us": [round(float(f5[: f5.size // 2].mean()), 1), round(float(f5[f5.size // 2:].mean()), 1)]}))
