@@ -305,7 +305,9 @@ int dql_stats_reset(dql_ctx* ctx);
  * stays in registers between them, so the state round trip through HBM and the launch boundary are paid once per P periods.
  * Table timing in units of launches is unchanged (a launch acts on every accumulator up to the launch before the previous one,
  * all P periods of a launch act on the same tables and add to the same accumulators; a per-step fold takes min(visits, P)
- * learning-rate steps per launch); P = 1 is the period-by-period schedule.  n_steps need not be a multiple of P. */
+ * learning-rate steps per launch); P = 1 is the period-by-period schedule.  n_steps need not be a multiple of P.
+ * "fair_prio" (-1 automatic, 0, 1): the waves that share a SIMD take turns at the issue priority (s_setprio by period + wave-slot parity) so that they finish a
+ * launch together instead of the older one first; automatic = when the context has more env waves than the device has SIMDs; 1 for contexts that share one GPU. */
 int dql_set_option(dql_ctx* ctx, const char* name, int32_t value);
 
 /* ---- episode log (Trainer promotion rule, pkg/trainer.py:218-232) ----

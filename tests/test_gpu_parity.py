@@ -836,3 +836,21 @@ def test_float32_preconditions_are_checked_not_assumed(mods):
             with pytest.raises(ValueError, match="roll_sp"):
                 e.set_fields(reals, ints)
         e.close()
+
+
+def test_issue_priority_alternation_changes_no_result(mods):
+    """Round 5: the waves that share a SIMD take turns at the issue priority (s_setprio by period + wave-slot parity; automatic when a context has more env
+    waves than the device SIMDs, option "fair_prio" 0 / 1 to force).  Scheduling only: every field and table stays bit-identical to the oracle with it forced
+    on in a small context (plain and literal-constant layouts, several waves per workgroup) and forced off."""
+    Engine, Oracle = mods
+    kw = dict(dtype=F32, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1)
+    for tick, fair in ((4, 1), (1, 1), (4, 0)):
+        eng = Engine(DqlConfig(**kw), 1500, seed=6); orc = Oracle(DqlConfig(**kw), 1500, seed=6)
+        eng.set_option("block", 256); eng.set_option("tick", tick); eng.set_option("fair_prio", fair)
+        eng.set_option("periods_per_launch", 5); orc.set_option("periods_per_launch", 5)
+        eng.train_steps(37, 0.4); orc.train_steps(37, 0.4)
+        _compare(eng, orc, exact=True, what=f"tick {tick} fair_prio {fair}")
+        eng.close()
+    e = Engine(DqlConfig(**kw), 64, seed=1)
+    with pytest.raises(ValueError):
+        e.set_option("fair_prio", 2)

@@ -15,6 +15,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 cohorts = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "4"])]
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+FAIR = int(sys.argv[5]) if len(sys.argv) > 5 else -1   # option "fair_prio" of every cohort's engine (-1: the library's automatic choice)
 cfg = dict(dtype=F32, fold_per_step=1, per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1)
 for C in cohorts:
     engs = []
@@ -22,6 +23,7 @@ for C in cohorts:
         lo, hi = shard_range(N, r, C)
         e = Engine(DqlConfig(**cfg), hi - lo, seed=42, env_id_offset=lo)
         e.set_option("periods_per_launch", P); e.set_option("tick", 4)
+        if FAIR >= 0: e.set_option("fair_prio", FAIR)
         engs.append(e)
     run = ShardedRunner(engs[0], LocalWindowReducer(engs[0]), sync_period=S) if C == 1 else ShardedGroup(engs, sync_period=S)
     run.train_steps(20 * P, 1.0); run.sync()
@@ -33,5 +35,5 @@ for C in cohorts:
     for e in engs: e.sync()
     wall = time.perf_counter() - t0
     d1 = sum(e.stats()["decisions"] for e in engs)
-    print(json.dumps({"envs": N, "cohorts": C, "periods_per_launch": P, "sync_period": S, "us_per_period": wall * 1e6 / steps, "env_steps_per_s": (d1 - d0) / wall}), flush=True)
+    print(json.dumps({"envs": N, "cohorts": C, "periods_per_launch": P, "sync_period": S, "fair_prio": FAIR, "us_per_period": wall * 1e6 / steps, "env_steps_per_s": (d1 - d0) / wall}), flush=True)
     for e in engs: e.close()
