@@ -33,6 +33,7 @@ for k in range(n_cfg):
     ppl = int(rng.choice([1, 1, 2, 3, 4, 8, 13, 16]))
     eng = Engine(DqlConfig(**kw), n, seed=seed); orc = Oracle(DqlConfig(**kw), n, seed=seed, n_threads=8)
     eng.set_option("block", block); eng.set_option("tick", tick)
+    eng.set_option("fair_prio", int(rng.integers(-1, 2)))   # round 5: issue-priority alternation (scheduling only: must change nothing)
     eng.set_option("periods_per_launch", ppl); orc.set_option("periods_per_launch", ppl)
     if windowed:
         eng.set_windowed(True); orc.set_windowed(True)
