@@ -571,25 +571,6 @@ def main():
                      "staleness_bound_periods": args.sync_period + 2 * max(args.sync_period, args.periods_per_launch),
                      "staleness_note": "a rank acts on tables that hold every rank's updates older than this many agent periods: the window in flight, the launch whose accumulators are being folded, and the launch in progress",
                      "exchange": EXCHANGE_TEXT[args.exchange], "replicas_identical": identical, **others}
-        # the OTHER exchange, same engine, same schedule, same run (its failure ends its leg, not the run: the line's value is already measured)
-        other = "p2p" if args.exchange == "rccl" else "rccl"
-        if other not in reducers:
-            sync_info[other] = {"skipped": p2p_setup_error}
-        else:
-            r_o = timed(args.sync_period, args.steps, args.warmup, red=reducers[other], reps=max(3, args.repeats // 2))
-            if r_o is None:
-                sync_info[other] = {"skipped": "the exchange failed inside its timed leg (a peer was not seen within p2p_spin_limit polls); see stderr"}
-            else:
-                (w_o, d_o, _), sp_o = median_rep(r_o)
-                ident_o = replicas_identical(eng, comm)
-                ms_o, n_o = exchange_device_ms(reducers[other])
-                sync_info[other] = {"value": d_o / w_o, "ms_per_step": w_o * 1e3 / args.steps, "sync_ms_per_step": (w_o - w_none) * 1e3 / args.steps, "exchange_device_ms": ms_o,
-                                    "exchanges_timed": n_o, "replicas_identical": ident_o, "value_min": sp_o["value_min"], "value_max": sp_o["value_max"], "exchange": EXCHANGE_TEXT[other]}
-        if "p2p" in reducers:
-            try:
-                sync_info["p2p_failed"] = eng.p2p_failed()
-            except Exception:  # noqa: BLE001
-                sync_info["p2p_failed"] = True
         if not identical:
             print(f"bench.py rank {rank}: the table replicas DIFFER between ranks after the final exchange ({args.exchange}): the run is invalid", file=sys.stderr)
             if comm:
@@ -624,6 +605,26 @@ def main():
     k_ms = dev_ms / n_launch if not multi else k_pairs_ms
     if not multi:
         dec_per_launch = decisions / n_launch  # average over the launches of the timed region (kernel_avg_ms is their average duration)
+    if multi:  # last use of the engine: a peer-to-peer leg that fails leaves dql_stats_get raising DQL_EPEER from then on
+        # the OTHER exchange, same engine, same schedule, same run (its failure ends its leg, not the run: the line's value is already measured)
+        other = "p2p" if args.exchange == "rccl" else "rccl"
+        if other not in reducers:
+            sync_info[other] = {"skipped": p2p_setup_error}
+        else:
+            r_o = timed(args.sync_period, args.steps, args.warmup, red=reducers[other], reps=max(3, args.repeats // 2))
+            if r_o is None:
+                sync_info[other] = {"skipped": "the exchange failed inside its timed leg (a peer was not seen within p2p_spin_limit polls); see stderr"}
+            else:
+                (w_o, d_o, _), sp_o = median_rep(r_o)
+                ident_o = replicas_identical(eng, comm)
+                ms_o, n_o = exchange_device_ms(reducers[other])
+                sync_info[other] = {"value": d_o / w_o, "ms_per_step": w_o * 1e3 / args.steps, "sync_ms_per_step": (w_o - w_none) * 1e3 / args.steps, "exchange_device_ms": ms_o,
+                                    "exchanges_timed": n_o, "replicas_identical": ident_o, "value_min": sp_o["value_min"], "value_max": sp_o["value_max"], "exchange": EXCHANGE_TEXT[other]}
+        if "p2p" in reducers:
+            try:
+                sync_info["p2p_failed"] = eng.p2p_failed()
+            except Exception:  # noqa: BLE001
+                sync_info["p2p_failed"] = True
     eng.close()
 
     curriculum = None
