@@ -496,8 +496,8 @@ def main():
     eng = Engine(cfg, args.envs, seed=42, device=dev_index, env_id_offset=rank * args.envs)
     eng.set_option("block", args.block)
     # any --steps K works: the engine cuts K periods into launches of at most P (the last one shorter)
-    if not 1 <= args.periods_per_launch <= 16:
-        print("bench.py: --periods-per-launch must be in 1..16", file=sys.stderr)
+    if not 1 <= args.periods_per_launch <= 32:
+        print("bench.py: --periods-per-launch must be in 1..32", file=sys.stderr)
         sys.exit(2)
     eng.set_option("periods_per_launch", args.periods_per_launch)
     # BOTH exchanges are set up on the one engine (round 5): the run's `value` is timed with --exchange (default RCCL), the other one gets its own

@@ -235,7 +235,7 @@ DQL_DEV double fold_cell(const FoldK& f, double* qa_m, double* cnt_m, long long*
 }
 
 #define DQL_ZERO_COPY_ENVS 16384  // up to here dql_step's kernel reads the host actions from pinned memory itself (no copy command)
-#define DQL_MAX_PERIODS 16  // agent periods one launch may run back to back per env (option "periods_per_launch")
+#define DQL_MAX_PERIODS 32  // agent periods one launch may run back to back per env (option "periods_per_launch"; round 5: 32, the schedule arrays' size)
 template <typename T> struct StepArgs {
   SimK<T> c;
   const MdpK<T> DQL_CONST_AS* mdp;  // device buffer, read as constant memory (scalar loads)
@@ -283,7 +283,7 @@ DQL_DEV long long wave_sum(long long v) {
 template <int BYTES> DQL_DEV void warm_kernarg() {
   const auto* p = __builtin_amdgcn_kernarg_segment_ptr();
   constexpr int L = (BYTES + 63) / 64;  // 64-byte lines the arguments reach (9 .. 17); offsets beyond the last line fold back onto it (a 17th line — float64 — is left to its first use)
-  static_assert(L > 8 && L <= 18, "adjust the touch list to the argument size");  // (sixteen lines are touched: float64's 17th and 18th are left to their first use)
+  static_assert(L > 8 && L <= 24, "adjust the touch list to the argument size");  // (sixteen lines are touched: what lies beyond — the tail of the per-period schedule arrays — is left to its first use)
 #define DQL_LINE(i) ((i) < L ? (i) * 64 : (L - 1) * 64)
   unsigned t0, t1, t2, t3, t4, t5, t6, t7, u0, u1, u2, u3, u4, u5, u6, u7;
   // sixteen loads in flight, one wait.  The first statement's destinations are inputs of the second, so the compiler keeps them allocated
@@ -1773,7 +1773,7 @@ int dql_set_option(dql_ctx* x, const char* name, int32_t value) {
   CHECK_CTX(x);
   if (!name) return fail(DQL_EINVAL, "null option name");
   if (!strcmp(name, "periods_per_launch")) {
-    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..16");
+    if (value < 1 || value > DQL_MAX_PERIODS) return fail(DQL_EINVAL, "periods_per_launch must be in 1..32");
     x->periods_per_launch = value;
     return DQL_OK;
   }

@@ -165,8 +165,8 @@ class Trainer:
         self._transfer_counts = float(transfer_counts)
         # (also starting level k - 1's slice over at every / every other restart of level k — "deep restarts" — moves the coin, it does not load it: of the two
         # seeds whose level 4 never reaches the gate one is cured and another seed breaks at level 2, profiles/r5_curriculum_deep_restart.jsonl; not kept)
-        if not 1 <= self._periods_per_launch <= 16 or self._chunk_steps % self._periods_per_launch:
-            raise ValueError("periods_per_launch must be in 1..16 and divide chunk_steps")
+        if not 1 <= self._periods_per_launch <= 32 or self._chunk_steps % self._periods_per_launch:
+            raise ValueError("periods_per_launch must be in 1..32 and divide chunk_steps")
         # device None: GPU LOCAL_RANK of a multi-rank launch (one process per GPU), GPU 0 of a single process; an explicit device wins
         self._comm = comm if comm is not None else RcclComm.from_env(device)  # None: single process
         self._device_arg = device

@@ -301,7 +301,7 @@ int dql_stats_reset(dql_ctx* ctx);
  * 500 Hz loop: 1 plain loop on scalar-register constants, 2 constants in vector registers + loop laid out per manager period, 3 the
  * packed float32 tick, 4 constants as instruction literals — float32 contexts whose vehicle / controller constants are the
  * reference's, DQL_EINVAL otherwise: same arithmetic, bit for bit, in all);
- * "periods_per_launch" P in 1..16 (default 1): dql_train_steps / dql_eval_steps run P agent periods per kernel launch — every env
+ * "periods_per_launch" P in 1..32 (default 1): dql_train_steps / dql_eval_steps run P agent periods per kernel launch — every env
  * stays in registers between them, so the state round trip through HBM and the launch boundary are paid once per P periods.
  * Table timing in units of launches is unchanged (a launch acts on every accumulator up to the launch before the previous one,
  * all P periods of a launch act on the same tables and add to the same accumulators; a per-step fold takes min(visits, P)

@@ -34,7 +34,7 @@ if __name__ == "__main__":
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--t-max", type=int, default=20)
     ap.add_argument("--judge-envs", type=int, default=1, help="whose episodes feed the promotion deque (1 = the reference's own situation, Trainer default)")
-    ap.add_argument("--periods-per-launch", type=int, default=1, help="agent periods per kernel launch, 1..16 (must divide --chunk and --sync-period)")
+    ap.add_argument("--periods-per-launch", type=int, default=1, help="agent periods per kernel launch, 1..32 (must divide --chunk and --sync-period)")
     ap.add_argument("--quirks", type=lambda v: int(v, 0), default=None, help="override of the mode's quirk set (include/dql.h DQL_Q_*), e.g. 0x60")
     ap.add_argument("--eps-tail", type=float, default=None, help="exploration rate of level 0 once the reference's schedule has decayed (default: the reference's 0.01 floor)")
     ap.add_argument("--eps-tail-after", type=float, default=0.0, help="... from this many episodes per env on")

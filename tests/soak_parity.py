@@ -30,7 +30,7 @@ for k in range(n_cfg):
     windowed = rng.random() < 0.3
     block = int(rng.choice([0, 0, 64, 128, 256, 512])) if kw["dtype"] == F32 else int(rng.choice([0, 0, 64, 128, 256]))
     tick = int(rng.integers(0, 5)) if kw["dtype"] == F32 else int(rng.integers(0, 4))   # 4 = literal constants: float32 + reference vehicle (the default config)
-    ppl = int(rng.choice([1, 1, 2, 3, 4, 8, 13, 16]))
+    ppl = int(rng.choice([1, 1, 2, 3, 4, 8, 13, 16, 24, 32]))
     eng = Engine(DqlConfig(**kw), n, seed=seed); orc = Oracle(DqlConfig(**kw), n, seed=seed, n_threads=8)
     eng.set_option("block", block); eng.set_option("tick", tick)
     eng.set_option("fair_prio", int(rng.integers(-1, 2)))   # round 5: issue-priority alternation (scheduling only: must change nothing)

@@ -785,7 +785,8 @@ def test_literal_tick_needs_reference_vehicle(mods):
                                           (2, 20000, 0, dict(two_axis=1, quirks=Q_PAPER)), (4, 70, 0, dict(dtype=F64, t_max=2.0, fold_per_step=1)),
                                           (8, 4096, 0, dict(t_max=3.0)), (8, 9000, 512, dict(fold_per_step=1, quirks=Q_PAPER)), (7, 300, 64, dict(dtype=F64, two_axis=1, t_max=2.0)),
                                           (16, 4096, 0, dict(t_max=3.0, fold_per_step=1)), (16, 9000, 256, dict(per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, quirks=Q_PAPER)),
-                                          (13, 300, 64, dict(dtype=F64, t_max=2.0))])
+                                          (13, 300, 64, dict(dtype=F64, t_max=2.0)), (32, 4096, 0, dict(t_max=3.0, fold_per_step=1)),
+                                          (32, 9000, 256, dict(per_env_platform=1, noise_pos_sd=0.25, noise_vel_sd=0.1, quirks=Q_PAPER)), (24, 200, 64, dict(dtype=F64, two_axis=1, t_max=2.0))])
 def test_periods_per_launch_bit_exact(mods, P, n, block, kw):
     """Option "periods_per_launch": P agent periods per kernel launch with the env in registers in between (one state round trip,
     one launch boundary, one table publication per P periods).  Same per-period arithmetic, RNG counters and tick schedule; the
@@ -814,7 +815,7 @@ def test_periods_per_launch_bit_exact(mods, P, n, block, kw):
     eng.flush(); orc.flush(); eng.apply_accum(); orc.apply_accum()
     _compare(eng, orc, exact=True, what="windowed")
     with pytest.raises(ValueError):
-        eng.set_option("periods_per_launch", 17)
+        eng.set_option("periods_per_launch", 33)
 
 
 def test_float32_preconditions_are_checked_not_assumed(mods):
