@@ -1,10 +1,17 @@
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5d; mkdir -p $O
-B="quirks=96,judge_envs=64,ppl=16,eps_tail=0.0,eps_tail_after=192,population_gate=0.94,sync_period=16,restart_after=96"
-python tools/exp_curriculum.py --envs 32768 --budget-per-env 768 --seeds 8 10 42 5 3 --set "deep2:$B,deep_restart_every=2" "deep1:$B,deep_restart_every=1" > $O/curr_deep.jsonl 2> $O/curr.err || { tail $O/curr.err; exit 1; }
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config_variants" > $O/pytest_depth.log 2>&1 || { tail -30 $O/pytest_depth.log; exit 1; }
+tail -2 $O/pytest_depth.log
+B="judge_envs=64,ppl=16,eps_tail=0.0,eps_tail_after=192,population_gate=0.94,sync_period=16,restart_after=96"
+python tools/exp_curriculum.py --envs 32768 --budget-per-env 768 --seeds 42 1 2 3 4 5 6 7 8 9 10 11 --set "d1:$B,quirks=352" "d2:$B,quirks=608" "d3:$B,quirks=864" > $O/curr_depth.jsonl 2> $O/curr.err || { tail $O/curr.err; exit 1; }
 python - <<'PY'
-import json
-for l in open('gpurun_out/r5d/curr_deep.jsonl'):
-    d=json.loads(l); print(d['set'], d['seed'], d['promoted_levels'], d['goal_hold'], d['touchdown'], d['wall_s'], [(x['level'], x['promoted'], x['pop'], x['episodes_per_env']) for x in d['levels']])
+import json, collections
+agg=collections.defaultdict(list)
+for l in open('gpurun_out/r5d/curr_depth.jsonl'):
+    d=json.loads(l); agg[d['set']].append(d)
+for k,v in agg.items():
+    print(k, 'all5', sum(1 for d in v if d['promoted_levels']==5), 'levels', [d['promoted_levels'] for d in v], 'goal mean %.3f min %.3f' % (sum(d['goal_hold'] for d in v)/len(v), min(d['goal_hold'] for d in v)), 'td mean %.3f min %.3f' % (sum(d['touchdown'] for d in v)/len(v), min(d['touchdown'] for d in v)), 'stage4 wall', round(sum(d['wall_to_stage4_s'] or 0 for d in v)/len(v),2))
+    for d in v:
+        if d['promoted_levels']<5: print('   ', d['seed'], [(x['level'], x['promoted'], x['pop'], x['episodes_per_env'], x['tail'].get('flyzone_x')) for x in d['levels']])
 PY
