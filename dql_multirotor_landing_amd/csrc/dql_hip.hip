@@ -305,8 +305,13 @@ template <int BYTES> DQL_DEV void warm_kernarg() {
 // 64 .. 256 threads: at most 2 waves per SIMD (68 KB of LDS accumulators per workgroup, or the register-hungry layouts); 512 threads:
 // two workgroups per CU = 4 waves per SIMD, so the compiler must stay within 128 VGPRs (it parks ~35 cold values in scratch)
 constexpr int step_waves_per_simd(int block) { return block == 512 ? 4 : 2; }
+// the register budget the compiler is HELD to (the minimum occupancy it must allow): 512-thread workgroups need their 4 waves per SIMD to fit a CU at all;
+// the float64 256-thread instance — the one big float64 batches run on — is held to 2 (256 VGPRs: 73 values go to scratch, none of them in the tick loop's
+// float64 chain): the float64 pipe issues every 8 cycles, one wave alone leaves it idle a quarter of the time (131 072 envs: 66.0 -> 57.7 us per period,
+// profiles/r5_f64_two_waves.jsonl; batches of one wave per SIMD pay 1 % for the spills).  Everything else may take up to 512 registers when it runs alone.
+constexpr int step_min_waves_per_simd(int block, int real_size) { return block >= 512 ? step_waves_per_simd(block) : (real_size == 8 && block == 256 ? 2 : 1); }
 template <typename T> DQL_DEV SimK<T> x_only(SimK<T> c) { c.two_axis = 0; return c; }
-template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? step_waves_per_simd(BLOCK) : 1, step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
+template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(step_min_waves_per_simd(BLOCK, (int)sizeof(T)), step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
   // global accumulators and the wave needs no LDS clear, no barrier and no flush scan (measured: -1.5 us of 26 at 4096 envs)

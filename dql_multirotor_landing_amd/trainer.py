@@ -88,7 +88,7 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
                "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after",
-               "population_gate", "env_kw", "restart_after", "transfer_counts")
+               "population_gate", "env_kw", "restart_after", "transfer_counts", "step_back_after", "max_step_backs")
 
 
 class Trainer:
@@ -102,7 +102,8 @@ class Trainer:
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
                  periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, population_gate: Optional[float] = None,
-                 env_kw: Optional[Dict[str, Any]] = None, restart_after: Optional[float] = None, transfer_counts: float = 0.0, comm=None, reducer_factory=None) -> None:
+                 env_kw: Optional[Dict[str, Any]] = None, restart_after: Optional[float] = None, transfer_counts: float = 0.0, step_back_after: Optional[int] = None, max_step_backs: int = 3,
+                 comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
             raise ValueError("mode must be 'reference' or 'paper'")
@@ -158,6 +159,15 @@ class Trainer:
         # 0.89-0.93 population success for their whole 768-episodes-per-env budget in round 4 while the other levels promoted within 4-80 episodes per
         # env (profiles/r4_bench_default_detail.json).  A restart is a fresh draw of that early phase; the promotion rule itself is untouched.
         self._restart_after = None if restart_after is None else float(restart_after)
+        # step_back_after (restarts; None = never): a level k >= 2 still not promoted after this many restarts is not restarted again — the trainer steps BACK one level:
+        # level k - 1 is started over from level k - 2 (transfer, cleared counters, the promotion rule as for any level) and level k after it.  Restarts redraw a level's
+        # fixed point from the SAME table of the level below; when every draw fails it is that table the level cannot be learnt from (12 seeds of the bench recipe: every
+        # level that is promoted at all needs at most 1 restart, the two seeds that fail level 4 fail it 8 times in a row, profiles/r5_bench_default_detail.json).
+        # At most `max_step_backs` per run (each costs at most two levels' budgets); the best attempt of a level survives its step-backs and is what a finally exhausted budget hands over.
+        self._step_back_after = None if step_back_after is None else int(step_back_after)
+        self._max_step_backs = int(max_step_backs)
+        if self._step_back_after is not None and (self._step_back_after < 1 or self._restart_after is None):
+            raise ValueError("step_back_after needs restart_after and must be >= 1 restart")
         # (exploration above level 0 — eps 0.02 / 0.05 / 0.1 for a level's first 32 / 64 episodes per env — was tried and ends learning: no level above 0
         # promoted in 4 of 4 seeds, profiles/r5_curriculum_upper_level_exploration.jsonl; the reference's "no exploration above level 0" stands)
         # transfer_counts f (default 0 = the reference: a new level's visit counters start at 0, so its first visits learn with alpha = 1, 0.70, 0.57 ...):
@@ -478,9 +488,14 @@ class Trainer:
             read_log = lambda: eng.episode_log_read(words=(j_cnt + 63) // 64)
         order = EpisodeOrder(j_valid.size, j_valid)
         first_level = self._working_curriculum_step
-        for self._working_curriculum_step in range(self._working_curriculum_step, self._curriculum_steps):
-            k = self._working_curriculum_step
+        k_next = first_level
+        first_promotion_wall: Dict[int, float] = {}
+        step_backs, best_of_level = 0, {}  # (step_back_after) steps back taken so far; best attempt of a level over its lineages
+        while k_next < self._curriculum_steps:
+            self._working_curriculum_step = k = k_next
+            k_next = k + 1
             resumed = resume is not None and k == first_level and resume.get("level") == k
+            resume = resume if resumed else None  # (a level entered again after a step back starts afresh)
             if resumed:
                 # continue the interrupted level: no transfer (it was applied when the level started), tables as checkpointed
                 have_envs = self._restore_env_state(eng, resume)
@@ -508,7 +523,8 @@ class Trainer:
             promoted = False
             promoted_at = None
             restarts, restart_base = (int(pr.get("restarts", 0)), int(pr.get("restart_base", 0))) if resumed else (0, 0)
-            best_attempt = None  # (population success rate, tables) of the best attempt given up so far (not checkpointed: a resumed run starts collecting again)
+            best_attempt = best_of_level.get(k)  # (population success rate, tables) of the best attempt given up so far (not checkpointed: a resumed run starts collecting again)
+            stalled = False
             info: Dict[str, Any] = {}
             while episodes < self._max_num_episodes:
                 sched_episode = int(episodes / self._eps_episode_scale)
@@ -553,6 +569,9 @@ class Trainer:
                     qa_, qb_, cnt = (np.asarray(t, dtype=np.float64).reshape(-1).copy() for t in eng.get_tables())
                     if best_attempt is None or rate > best_attempt[0]:  # the attempt given up may still be the best one the budget buys
                         best_attempt = (rate, qa_, qb_, cnt.copy())
+                    if (self._step_back_after is not None and k >= 2 and k - 1 >= first_level and restarts >= self._step_back_after and step_backs < self._max_step_backs):
+                        stalled = True  # every redraw from this table of level k - 1 failed: step back instead of restarting again (see __init__)
+                        break
                     per_level = cnt.size // 5
                     cnt[k * per_level:(k + 1) * per_level] = np.floor(self._transfer_counts * cnt[(k - 1) * per_level:k * per_level]) if self._transfer_counts > 0.0 else 0.0
                     eng.set_tables(count=cnt)
@@ -575,15 +594,31 @@ class Trainer:
                     break
                 if self._max_steps_per_level is not None and steps >= self._max_steps_per_level:
                     break
+            if stalled:
+                best_of_level[k] = best_attempt
+                step_backs += 1
+                cnt = np.asarray(eng.get_tables()[2], dtype=np.float64).reshape(-1).copy()
+                per_level = cnt.size // 5
+                cnt[(k - 1) * per_level:(k + 1) * per_level] = 0.0  # levels k - 1 and k learn again from fresh counters; their slices are rewritten by the transfers
+                eng.set_tables(count=cnt)
+                while self.history and self.history[-1]["level"] >= k - 1:  # one entry per level: level k - 1's is written again when it ends again
+                    self.history.pop()
+                self._progress = None
+                k_next = k - 1
+                continue
             exhausted = not promoted and episodes >= self._max_num_episodes
             if exhausted and best_attempt is not None and best_attempt[0] > (info.get("Success rate") or 0.0):
                 # the budget ran out in a later, worse attempt: the level hands over the tables of its best one (same rule as the reference's budget
                 # hand-over, pkg/trainer.py:187 — it just does not hand over a restart that had barely begun)
                 eng.set_tables(best_attempt[1], best_attempt[2], best_attempt[3])
                 info["Success rate"] = best_attempt[0]
-            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "restarts": restarts, "episodes": episodes,
+            if promoted and k not in first_promotion_wall:
+                first_promotion_wall[k] = time.perf_counter() - t_start
+            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "restarts": restarts, "step_backs": step_backs, "episodes": episodes,
                                  "agent_periods": steps, "success_rate": info.get("Success rate"),
-                                 "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start})
+                                 "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start,
+                                 # (with step backs a level can end more than once: when the rule FIRST promoted it — "stage k + 1 entered")
+                                 "wall_first_promoted_s": first_promotion_wall.get(k)})
             if self._mode == "reference":
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))

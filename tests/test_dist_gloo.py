@@ -407,3 +407,24 @@ def test_level_restart_on_plateau(tmp_path, monkeypatch):
     assert np.isfinite(qa_a).all() and not np.array_equal(qa_a, qb_ := qa_b)                 # the restarts changed the course of level 1
     np.testing.assert_array_equal(np.asarray(qa_a).reshape(5, -1)[2:], 0.0)                  # and touched no level above it
     assert np.asarray(cnt_a).reshape(5, -1)[1].sum() < np.asarray(cnt_b).reshape(5, -1)[1].sum()   # counters of the level were cleared on the way
+
+
+def test_step_back_after_failed_restarts(tmp_path, monkeypatch):
+    """Round 5, Trainer(step_back_after=...): a level k >= 2 that has used up that many restarts steps BACK — level k - 1 is started over from level k - 2
+    and level k after it (the restarts had been redrawing level k from one and the same table of level k - 1).  One history entry per level whatever the
+    path, `step_backs` counts them, at most `max_step_backs` per run; level 1 never steps back (level 0 is not restarted); without the keyword nothing changes."""
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    kw = dict(curriculum_steps=3, n_envs=48, chunk_steps=8, checkpoint_every=10**9, max_num_episodes=500, t_max=3, mode="paper", judge_envs=16,
+              successive_successful_episodes=10, eps_floor=0.3, success_rate=2.0, restart_after=1.5)
+    a = T.Trainer(save_path=tmp_path / "a", step_back_after=1, max_step_backs=2, **kw)
+    ha = a.curriculum_training()
+    assert [h["level"] for h in ha] == [0, 1, 2] and not any(h["promoted"] for h in ha)
+    assert ha[2]["step_backs"] == 2 and ha[1]["step_backs"] >= 1 and ha[0]["step_backs"] == 0   # level 2 gave up twice; level 1's entry is of its last run
+    assert ha[2]["exhausted"] and ha[2]["restarts"] >= 2                                        # once the steps back are spent the level restarts to its budget's end
+    b = T.Trainer(save_path=tmp_path / "b", **kw)
+    hb = b.curriculum_training()
+    assert [h["step_backs"] for h in hb] == [0, 0, 0]
+    assert np.isfinite(a._engine.get_tables()[0]).all()
+    with pytest.raises(ValueError, match="step_back_after"):
+        T.Trainer(save_path=tmp_path / "c", step_back_after=1, **{**kw, "restart_after": None})

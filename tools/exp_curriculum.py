@@ -56,13 +56,13 @@ for spec in a.set:
                        ("TERMINAL_SUCCESS", "TERMINAL_FLYZONE_X", "TERMINAL_TIMEOUT", "TERMINAL_MINIMUM_ALTITUDE", "TERMINAL_FLYZONE_Z", "TERMINAL_CONTACT")}
                 n_ep = max(1.0, sum(tot.values()))
                 levels.append({"level": h["level"], "promoted": h["promoted"], "pop": None if h["success_rate"] is None else round(h["success_rate"], 3), "episodes_per_env": round(h["episodes"] / envs, 1), "periods": h["agent_periods"],
-                               "tail": {k.replace("TERMINAL_", "").lower(): round(v / n_ep, 3) for k, v in tot.items() if v}})
+                               "restarts": h.get("restarts", 0), "step_backs": h.get("step_backs", 0), "tail": {k.replace("TERMINAL_", "").lower(): round(v / n_ep, 3) for k, v in tot.items() if v}})
             wk = kw.get("env_kw") or {}  # evaluated in the world it was trained in
             ev_t = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="training", quirks=Q_PAPER, **wk)
             ev_s = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="simulation", quirks=Q_PAPER, **wk)
             tr._engine.close()
         print(json.dumps({"set": name, "kw": kw, "envs": envs, "budget_per_env": budget_per_env, "seed": seed, "wall_s": round(wall, 2),
-                          "wall_to_stage4_s": round(hist[3]["wall_since_start_s"], 2) if len(hist) > 3 else None,
+                          "wall_to_stage4_s": round(hist[3].get("wall_first_promoted_s") or hist[3]["wall_since_start_s"], 2) if len(hist) > 3 else None,
                           "promoted_levels": sum(1 for h in hist if h["promoted"]), "goal_hold": round(ev_t["TERMINAL_SUCCESS"] / a.eval_envs, 3),
                           "touchdown": round(ev_s["TERMINAL_CONTACT"] / a.eval_envs, 3), "flyzone_landing": round(ev_s["TERMINAL_FLYZONE_X"] / a.eval_envs, 3),
                           "levels": levels}), flush=True)
