@@ -88,7 +88,7 @@ LOG_COLUMNS = (["Curriculum step", "Curriculum episode count", "Curent episode",
 # constructor keywords that are not in the reference; saved in trainer.json and restored by load()
 _BUILD_KEYS = ("n_envs", "device", "dtype", "mode", "chunk_steps", "checkpoint_every", "max_steps_per_level", "quiet", "fold_per_step", "eps_floor",
                "promotion_rule", "sync_period", "judge_envs", "eps_episode_scale", "quirks", "checkpoint_env_state", "periods_per_launch", "eps_tail", "eps_tail_after",
-               "population_gate", "env_kw", "restart_after", "transfer_counts", "step_back_after", "max_step_backs", "final_candidates", "final_eval_envs")
+               "population_gate", "env_kw", "restart_after", "transfer_counts", "step_back_after", "max_step_backs")
 
 
 class Trainer:
@@ -102,7 +102,7 @@ class Trainer:
                  fold_per_step: int = 1, eps_floor: float = 0.0, promotion_rule: str = "ordered", sync_period: Optional[int] = None,
                  judge_envs: Optional[int] = 1, eps_episode_scale: float = 1.0, quirks: Optional[int] = None, checkpoint_env_state: bool = True,
                  periods_per_launch: int = 1, eps_tail: Optional[float] = None, eps_tail_after: float = 0.0, population_gate: Optional[float] = None,
-                 env_kw: Optional[Dict[str, Any]] = None, restart_after: Optional[float] = None, transfer_counts: float = 0.0, step_back_after: Optional[int] = None, max_step_backs: int = 3, final_candidates: int = 1, final_eval_envs: int = 4096,
+                 env_kw: Optional[Dict[str, Any]] = None, restart_after: Optional[float] = None, transfer_counts: float = 0.0, step_back_after: Optional[int] = None, max_step_backs: int = 3,
                  comm=None, reducer_factory=None) -> None:
         np.random.seed(seed)
         if mode not in ("reference", "paper"):
@@ -166,14 +166,6 @@ class Trainer:
         # At most `max_step_backs` per run (each costs at most two levels' budgets); the best attempt of a level survives its step-backs and is what a finally exhausted budget hands over.
         self._step_back_after = None if step_back_after is None else int(step_back_after)
         self._max_step_backs = int(max_step_backs)
-        # final_candidates K > 1 (paper mode): the LAST level is learnt K times from the same tables of the level below (each time to its promotion or to the end of its
-        # budget, like any level), every outcome is flown greedily in the landing flavour (evaluation.landing_score: final_eval_envs envs, its own seed — not the
-        # evaluation harness's), and the run ends on the tables that land best among the promoted candidates (among all when none was promoted).  The rule decides WHETHER a
-        # level is learnt; between fixed points that all pass it, touchdown rates spread over 0.82-0.93 (profiles/r5_bench_default_detail.json) — this picks among them
-        # by validation.  Every rank evaluates the same tables with the same seed: the same choice everywhere, no exchange.
-        self._final_candidates, self._final_eval_envs = int(final_candidates), int(final_eval_envs)
-        if self._final_candidates < 1:
-            raise ValueError("final_candidates must be >= 1")
         if self._step_back_after is not None and (self._step_back_after < 1 or self._restart_after is None):
             raise ValueError("step_back_after needs restart_after and must be >= 1 restart")
         # (exploration above level 0 — eps 0.02 / 0.05 / 0.1 for a level's first 32 / 64 episodes per env — was tried and ends learning: no level above 0
@@ -498,7 +490,6 @@ class Trainer:
         first_level = self._working_curriculum_step
         k_next = first_level
         first_promotion_wall: Dict[int, float] = {}
-        candidates = []  # (final_candidates) outcomes of the last level so far: (landing score, promoted, tables, history entry)
         step_backs, best_of_level = 0, {}  # (step_back_after) steps back taken so far; best attempt of a level over its lineages
         while k_next < self._curriculum_steps:
             self._working_curriculum_step = k = k_next
@@ -628,28 +619,6 @@ class Trainer:
                                  "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start,
                                  # (with step backs a level can end more than once: when the rule FIRST promoted it — "stage k + 1 entered")
                                  "wall_first_promoted_s": first_promotion_wall.get(k)})
-            if (self._final_candidates > 1 and self._mode == "paper" and k == self._curriculum_steps - 1 and k >= 1 and (promoted or exhausted)):
-                from .evaluation import landing_score
-                tabs = tuple(np.asarray(t, dtype=np.float64).reshape(-1).copy() for t in eng.get_tables())
-                sc = landing_score(Engine, tabs, level=k, n_envs=self._final_eval_envs, dtype=self._dtype, device=self._device, quirks=Q_PAPER, **(self._env_kw or {}))
-                candidates.append((sc["touchdown_rate"], promoted, tabs, self.history.pop()))
-                if len(candidates) < self._final_candidates:
-                    cnt = tabs[2].copy()
-                    per_level = cnt.size // 5
-                    cnt[k * per_level:(k + 1) * per_level] = 0.0   # the level learns again from the level below: fresh counters, its slice rewritten by the transfer
-                    eng.set_tables(count=cnt)
-                    best_of_level.pop(k, None)
-                    self._progress = None
-                    k_next = k
-                    continue
-                pool = [i for i, c in enumerate(candidates) if c[1]] or list(range(len(candidates)))
-                best = max(pool, key=lambda i: candidates[i][0])
-                eng.set_tables(*candidates[best][2])
-                entry = dict(candidates[best][3])
-                entry.update({"final_candidates": [{"landing_score": c[0], "promoted": c[1]} for c in candidates], "selected": best,
-                              "wall_s": sum(c[3]["wall_s"] for c in candidates), "wall_since_start_s": time.perf_counter() - t_start})
-                self.history.append(entry)
-                promoted, exhausted = entry["promoted"], entry["exhausted"]
             if self._mode == "reference":
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))

@@ -428,28 +428,3 @@ def test_step_back_after_failed_restarts(tmp_path, monkeypatch):
     assert np.isfinite(a._engine.get_tables()[0]).all()
     with pytest.raises(ValueError, match="step_back_after"):
         T.Trainer(save_path=tmp_path / "c", step_back_after=1, **{**kw, "restart_after": None})
-
-
-def test_final_candidates_pick_the_tables_that_land_best(tmp_path, monkeypatch):
-    """Round 5, Trainer(final_candidates=K): the last level is learnt K times from the same tables of the level below, every outcome is flown greedily in the
-    landing flavour (evaluation.landing_score on the Trainer's engine class) and the run ends on the best-landing candidate; one history entry for the level,
-    carrying every candidate's score and the choice.  K = 1 (default) is the Trainer as it was."""
-    import dql_multirotor_landing_amd.trainer as T
-    from dql_multirotor_landing_amd.evaluation import landing_score
-    OE = _oracle_engine_class()
-    monkeypatch.setattr(T, "Engine", OE)
-    kw = dict(curriculum_steps=2, n_envs=48, chunk_steps=8, checkpoint_every=10**9, max_num_episodes=150, t_max=3, mode="paper", judge_envs=16,
-              successive_successful_episodes=10, eps_floor=0.3, success_rate=2.0, final_eval_envs=64)
-    a = T.Trainer(save_path=tmp_path / "a", final_candidates=3, **kw)
-    ha = a.curriculum_training()
-    assert [h["level"] for h in ha] == [0, 1]
-    fc = ha[1]["final_candidates"]
-    assert len(fc) == 3 and ha[1]["selected"] == max(range(3), key=lambda i: fc[i]["landing_score"]) and all(0.0 <= c["landing_score"] <= 1.0 for c in fc)
-    # the engine holds the selected candidate's tables: scoring them again gives the selected score
-    again = landing_score(OE, a._engine.get_tables(), level=1, n_envs=64, dtype=a._dtype, quirks=T.Q_PAPER)
-    assert again["touchdown_rate"] == fc[ha[1]["selected"]]["landing_score"]
-    b = T.Trainer(save_path=tmp_path / "b", **kw)
-    hb = b.curriculum_training()
-    assert "final_candidates" not in hb[1]
-    with pytest.raises(ValueError):
-        T.Trainer(save_path=tmp_path / "c", final_candidates=0, **kw)

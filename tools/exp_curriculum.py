@@ -56,8 +56,7 @@ for spec in a.set:
                        ("TERMINAL_SUCCESS", "TERMINAL_FLYZONE_X", "TERMINAL_TIMEOUT", "TERMINAL_MINIMUM_ALTITUDE", "TERMINAL_FLYZONE_Z", "TERMINAL_CONTACT")}
                 n_ep = max(1.0, sum(tot.values()))
                 levels.append({"level": h["level"], "promoted": h["promoted"], "pop": None if h["success_rate"] is None else round(h["success_rate"], 3), "episodes_per_env": round(h["episodes"] / envs, 1), "periods": h["agent_periods"],
-                               "restarts": h.get("restarts", 0), "step_backs": h.get("step_backs", 0),
-                               **({"final_candidates": [round(c["landing_score"], 3) for c in h["final_candidates"]], "selected": h["selected"]} if "final_candidates" in h else {}), "tail": {k.replace("TERMINAL_", "").lower(): round(v / n_ep, 3) for k, v in tot.items() if v}})
+                               "restarts": h.get("restarts", 0), "step_backs": h.get("step_backs", 0), "tail": {k.replace("TERMINAL_", "").lower(): round(v / n_ep, 3) for k, v in tot.items() if v}})
             wk = kw.get("env_kw") or {}  # evaluated in the world it was trained in
             ev_t = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="training", quirks=Q_PAPER, **wk)
             ev_s = simulation.evaluate(Path(d) / "run", a.eval_envs, 4, flavour="simulation", quirks=Q_PAPER, **wk)
