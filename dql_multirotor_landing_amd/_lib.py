@@ -12,7 +12,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("DQL_LIB_PATH", CSRC / "libdql_hip.so"))  # override: A/B builds of the kernel
 
 OK, EINVAL, EHIP, ESTATE, ENOMEM, ERCCL, EPEER = 0, -1, -2, -3, -4, -5, -6
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 P2P_MAX_RANKS = 8
@@ -119,6 +119,8 @@ SYMBOLS = {
     "dql_agent_update_resident": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "dql_agent_mirror_predict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "dql_agent_mirror_update": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _dbl, _dbl, _dbl, C.c_uint32, C.c_int32, C.c_int32]),
+    "dql_agent_mirror_update_deferred": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _dbl, _dbl, _dbl, C.c_uint32, C.c_int32, C.c_int32]),
+    "dql_agent_mirror_complete": (C.c_int, [_vp]),
     "dql_agent_transfer": (C.c_int, [C.c_int, _vp, _vp, _i32, _dbl]),
     "dql_agent_predict": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "dql_agent_update": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _i64, C.c_uint32, _vp, _vp]),

@@ -2088,7 +2088,10 @@ struct dql_agent {
   int next_idx = -1, next_action = 0;
   unsigned seq = 0;
   void* post = nullptr; void* post_dev = nullptr;  // the mirror calls' own pinned page: [0] AgentOneOut, [64] predict's index, [128] its answer
+  // dql_agent_mirror_update_deferred: an update whose kernel is in flight and whose cell has not been patched into the caller's arrays yet
+  bool pending = false; double* p_q = nullptr; double* p_count = nullptr; int p_sa = 0, p_t = 0, p_ns = -1; unsigned p_seq = 0;
 };
+static int mirror_complete(dql_agent* a);
 static int agent_pin(dql_agent* a, size_t bytes) {
   if (bytes <= a->pin_bytes) return DQL_OK;
   if (a->pin) { HIP_TRY(hipStreamSynchronize(a->stream)); HIP_TRY(hipHostFree(a->pin)); a->pin = nullptr; a->pin_bytes = 0; }
@@ -2138,6 +2141,7 @@ int dql_agent_destroy(dql_agent* a) {
 }
 int dql_agent_set_tables(dql_agent* a, const double* qa, const double* qb, const double* count) {
   CHECK_AGENT(a);
+  { int rc = mirror_complete(a); if (rc) return rc; }
   HIP_TRY(hipSetDevice(a->device));
   const size_t B = DQL_N_CELLS * sizeof(double);
   if (qa) HIP_TRY(hipMemcpyAsync(a->qa, qa, B, hipMemcpyHostToDevice, a->stream));
@@ -2149,6 +2153,7 @@ int dql_agent_set_tables(dql_agent* a, const double* qa, const double* qb, const
 }
 int dql_agent_get_tables(dql_agent* a, double* qa, double* qb, double* count) {
   CHECK_AGENT(a);
+  { int rc = mirror_complete(a); if (rc) return rc; }
   HIP_TRY(hipSetDevice(a->device));
   const size_t B = DQL_N_CELLS * sizeof(double);
   if (qa) HIP_TRY(hipMemcpyAsync(qa, a->qa, B, hipMemcpyDeviceToHost, a->stream));
@@ -2159,6 +2164,7 @@ int dql_agent_get_tables(dql_agent* a, double* qa, double* qb, double* count) {
 }
 int dql_agent_predict_resident(dql_agent* a, const int32_t* idx, int64_t n, uint8_t* action_out) {
   CHECK_AGENT(a);
+  { int rc = mirror_complete(a); if (rc) return rc; }
   if (n < 0 || (n > 0 && (!idx || !action_out))) return fail(DQL_EINVAL, "null array");
   if (n == 0) return DQL_OK;
   for (int64_t i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= DQL_N_STATES) return fail(DQL_EINVAL, "state index out of range");
@@ -2176,6 +2182,7 @@ int dql_agent_predict_resident(dql_agent* a, const int32_t* idx, int64_t n, uint
 int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns, const double* alpha, double gamma, const double* reward, int64_t n,
                               uint32_t quirks, const uint8_t* coin, const uint8_t* done, double* q_new, double* count_new, uint8_t* next_action) {
   CHECK_AGENT(a);
+  { int rc = mirror_complete(a); if (rc) return rc; }
   if (n < 0 || (n > 0 && (!sa || !ns || !alpha || !reward))) return fail(DQL_EINVAL, "null array");
   if (n == 0) return DQL_OK;
   if (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && !coin) return fail(DQL_EINVAL, "Double Q-learning (DQL_Q_UPDATE_TABLE_A_ONLY cleared) needs the caller's coin per transition");
@@ -2197,8 +2204,22 @@ int dql_agent_update_resident(dql_agent* a, const int32_t* sa, const int32_t* ns
 }
 // ---- host-mirrored single transitions ----
 // brings the device tables up to the caller's arrays; what changed is found by comparing with the shadow of the last upload
+// a deferred update's second half: wait for its kernel (it has usually finished while the caller was busy), patch the one cell and its visit counter into
+// the caller's arrays and into the shadow, keep the kernel's answer for the next predict
+static int mirror_complete(dql_agent* a) {
+  if (!a->pending) return DQL_OK;
+  a->pending = false;
+  HIP_TRY(hipSetDevice(a->device));
+  AgentOneOut* o = (AgentOneOut*)a->post;
+  if (!wait_posted(&o->seq, a->p_seq)) HIP_TRY(wait_stream(a->stream));
+  a->p_q[a->p_sa] = o->q_new; a->p_count[a->p_sa] = o->count_new;
+  a->shadow[(size_t)a->p_t * DQL_N_CELLS + a->p_sa] = o->q_new; a->shadow[(size_t)2 * DQL_N_CELLS + a->p_sa] = o->count_new;
+  a->next_idx = a->p_ns; a->next_action = o->next_action;
+  return DQL_OK;
+}
 static int mirror_refresh(dql_agent* a, const double* qa, const double* qb, const double* count, int32_t n_levels) {
   if (!qa || !qb || !count) return fail(DQL_EINVAL, "null table");
+  { int rc = mirror_complete(a); if (rc) return rc; }
   if (n_levels < 1 || n_levels > DQL_MAX_LEVELS) return fail(DQL_EINVAL, "n_levels must be in 1..5");
   HIP_TRY(hipSetDevice(a->device));
   const size_t B = DQL_N_CELLS * sizeof(double), used = (size_t)n_levels * DQL_STATES_PER_LEVEL * 3 * sizeof(double);
@@ -2234,21 +2255,27 @@ int dql_agent_mirror_predict(dql_agent* a, const double* qa, const double* qb, c
   *action_out = *((const uint8_t*)a->post + 128);
   return DQL_OK;
 }
-int dql_agent_mirror_update(dql_agent* a, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha, double gamma,
-                            double reward, uint32_t quirks, int32_t coin, int32_t done) {
+int dql_agent_mirror_update_deferred(dql_agent* a, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha, double gamma,
+                                     double reward, uint32_t quirks, int32_t coin, int32_t done) {
   CHECK_AGENT(a);
   { int rc = mirror_refresh(a, qa, qb, count, n_levels); if (rc) return rc; }
   if (sa < 0 || sa >= n_levels * DQL_STATES_PER_LEVEL * 3 || ns < 0 || ns >= n_levels * DQL_STATES_PER_LEVEL) return fail(DQL_EINVAL, "index outside the table's levels");
-  AgentOneOut* o = (AgentOneOut*)a->post;
   const unsigned seq = ++a->seq;
   hipLaunchKernelGGL(k_update_one, dim3(1), dim3(64), 0, a->stream, a->qa, a->qb, a->count, (int)sa, (int)ns, alpha, gamma, reward, quirks, (int)coin, (int)done, (AgentOneOut*)a->post_dev, seq);
   HIP_TRY(hipGetLastError());
-  if (!wait_posted(&o->seq, seq)) HIP_TRY(wait_stream(a->stream));
-  const int t = (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && coin) ? 1 : 0;  // the table agent_update_one wrote
-  (t ? qb : qa)[sa] = o->q_new; count[sa] = o->count_new;
-  a->shadow[(size_t)t * DQL_N_CELLS + sa] = o->q_new; a->shadow[(size_t)2 * DQL_N_CELLS + sa] = o->count_new;
-  a->next_idx = ns; a->next_action = o->next_action;
+  const int t = (!(quirks & DQL_Q_UPDATE_TABLE_A_ONLY) && coin) ? 1 : 0;  // the table agent_update_one writes
+  a->pending = true; a->p_q = t ? qb : qa; a->p_count = count; a->p_sa = sa; a->p_t = t; a->p_ns = ns; a->p_seq = seq;
+  a->next_idx = -1;  // (the device tables are ahead of the caller's arrays until mirror_complete)
   return DQL_OK;
+}
+int dql_agent_mirror_complete(dql_agent* a) {
+  CHECK_AGENT(a);
+  return mirror_complete(a);
+}
+int dql_agent_mirror_update(dql_agent* a, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha, double gamma,
+                            double reward, uint32_t quirks, int32_t coin, int32_t done) {
+  const int rc = dql_agent_mirror_update_deferred(a, qa, qb, count, n_levels, sa, ns, alpha, gamma, reward, quirks, coin, done);
+  return rc ? rc : mirror_complete(a);
 }
 
 int dql_agent_transfer(int device, double* qa, double* qb, int32_t k, double ratio) {

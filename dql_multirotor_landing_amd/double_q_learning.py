@@ -38,14 +38,29 @@ class DoubleQLearningAgent:
         self.mode = mode
         self.curriculum_steps = curriculum_steps
         shape = (curriculum_steps,) + TABLE_SHAPE[1:]
+        self._pending = False  # an update whose cell the library has not patched into the arrays below yet (see `update`)
+        self._res = None      # dql_agent*: the tables resident on the device between calls (created on first use)
         self.Q_table_a = np.zeros(shape)
         self.Q_table_b = np.zeros(shape)
         self.state_action_counter = np.zeros(shape)
         self._device = device
         self._lib = None
-        self._res = None      # dql_agent*: the tables resident on the device between calls (created on first use)
         self._bound = None    # (Q_table_a, Q_table_b, state_action_counter) objects whose buffer addresses self._ptrs holds
         self._ptrs = None
+
+    # ---- the three public tables (pkg/double_q_learning.py:35-40).  Plain numpy arrays, readable, writable and replaceable at any time, as in the reference;
+    # they are properties only so that reading or replacing one first lets the library finish an update it still has in flight (`update` returns when the
+    # kernel is launched; the one changed cell and its visit counter are patched into these arrays at the next access through the agent, whatever it is) ----
+    def _complete(self):
+        if self._pending:
+            self._pending = False
+            rc = self._lib.dql_agent_mirror_complete(self._res)
+            if rc:
+                _lib.check(rc)
+
+    Q_table_a = property(lambda self: (self._complete(), self._qa)[1], lambda self, v: (self._complete(), setattr(self, "_qa", v))[0])
+    Q_table_b = property(lambda self: (self._complete(), self._qb)[1], lambda self, v: (self._complete(), setattr(self, "_qb", v))[0])
+    state_action_counter = property(lambda self: (self._complete(), self._cnt)[1], lambda self, v: (self._complete(), setattr(self, "_cnt", v))[0])
 
     # ---- resident device tables, mirrored from the public host arrays (include/dql.h dql_agent_mirror_*) ----
     def _resident(self):
@@ -63,7 +78,7 @@ class DoubleQLearningAgent:
             self._res = h
             self._act = C.c_uint8(0)
             self._act_ref = C.byref(self._act)
-        a, b, c = self.Q_table_a, self.Q_table_b, self.state_action_counter
+        a, b, c = self._qa, self._qb, self._cnt  # (the raw attributes: the library call that follows completes a pending update itself)
         bound = self._bound
         if bound is None or a is not bound[0] or b is not bound[1] or c is not bound[2]:
             shape = (self.curriculum_steps,) + TABLE_SHAPE[1:]
@@ -74,13 +89,15 @@ class DoubleQLearningAgent:
                 if t.shape != shape:
                     raise ValueError(f"table of shape {t.shape}, expected {shape}")
                 fixed.append(t)
-            a, b, c = self.Q_table_a, self.Q_table_b, self.state_action_counter = fixed
+            self._complete()  # (before the arrays the pending patch points into are let go)
+            a, b, c = self._qa, self._qb, self._cnt = fixed
             self._bound = (a, b, c)
             self._ptrs = tuple(t.ctypes.data for t in fixed)
         return lib, self._res, self._ptrs, self.curriculum_steps
 
     def close(self):
         if getattr(self, "_res", None):
+            self._complete()
             _lib.load().dql_agent_destroy(self._res)
             self._res = None
 
@@ -172,13 +189,16 @@ class DoubleQLearningAgent:
         lib, res, (pa, pb, pc), n = self._resident()
         cell = ((((sa[0] * 3 + sa[1]) * 3 + sa[2]) * 3 + sa[3]) * 7 + sa[4]) * 3 + sa[5]
         nidx = (((ns[0] * 3 + ns[1]) * 3 + ns[2]) * 3 + ns[3]) * 7 + ns[4]
-        # the library patches the one changed cell and its visit counter into Q_table_a / _b / state_action_counter itself
+        # the library patches the one changed cell and its visit counter into Q_table_a / _b / state_action_counter itself — when the kernel launched here has
+        # finished: at the next call on this agent or the next read of a table through it (`_complete`), so the kernel's round trip hides behind whatever the
+        # caller does between update() and its next guess() (the reference's loop: logging, the success deque, pkg/trainer.py:204-232)
         if self.mode == "reference":
-            rc = lib.dql_agent_mirror_update(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_REFERENCE, 0, 0)
+            rc = lib.dql_agent_mirror_update_deferred(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_REFERENCE, 0, 0)
         else:
-            rc = lib.dql_agent_mirror_update(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_PAPER, 0 if u < 0.5 else 1, 1 if done else 0)
+            rc = lib.dql_agent_mirror_update_deferred(res, pa, pb, pc, n, cell, nidx, float(alpha), float(gamma), float(reward), Q_PAPER, 0 if u < 0.5 else 1, 1 if done else 0)
         if rc:
             _lib.check(rc)
+        self._pending = True
 
     # ---- pkg/double_q_learning.py:110-124 ----
     def guess(self, state: State, exploration_rate: float):
@@ -192,6 +212,7 @@ class DoubleQLearningAgent:
         lib, res, (pa, pb, pc), n = self._resident()
         # answered from the last update's kernel when that update's next state is asked for and the tables were not written since
         rc = lib.dql_agent_mirror_predict(res, pa, pb, pc, n, (((s[0] * 3 + s[1]) * 3 + s[2]) * 3 + s[3]) * 7 + s[4], self._act_ref)
+        self._pending = False  # (every mirror call completes a pending update first)
         if rc:
             _lib.check(rc)
         return self._act.value

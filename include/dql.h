@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DQL_ABI_VERSION 5 /* 5: tick replay operators (dql_*_run), measurement symbols moved to dql_diag.h as dql_diag_* */
+#define DQL_ABI_VERSION 6 /* 6: dql_agent_mirror_update_deferred / _complete; 5: tick replay operators (dql_*_run), measurement symbols moved to dql_diag.h as dql_diag_* */
 
 typedef enum dql_status {
   DQL_OK = 0,
@@ -408,6 +408,13 @@ int dql_agent_update_resident(dql_agent* agent, const int32_t* sa, const int32_t
 int dql_agent_mirror_predict(dql_agent* agent, const double* qa, const double* qb, const double* count, int32_t n_levels, int32_t idx, uint8_t* action_out);
 int dql_agent_mirror_update(dql_agent* agent, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha,
                             double gamma, double reward, uint32_t quirks, int32_t coin, int32_t done);
+/* The same update in two halves (ABI v6): _deferred launches the kernel and returns — the caller's arrays still hold the OLD cell; dql_agent_mirror_complete, or the next
+ * call of any kind on this agent, waits for the kernel and patches the cell and its visit counter in (into the arrays that were passed to _deferred: they must stay alive
+ * until then).  For a host loop that has other work between update() and the next guess() (the reference's has: pkg/trainer.py:204-212) the kernel's round trip hides
+ * behind that work.  dql_agent_mirror_update == _deferred + _complete. */
+int dql_agent_mirror_update_deferred(dql_agent* agent, double* qa, double* qb, double* count, int32_t n_levels, int32_t sa, int32_t ns, double alpha,
+                                     double gamma, double reward, uint32_t quirks, int32_t coin, int32_t done);
+int dql_agent_mirror_complete(dql_agent* agent);
 /* DoubleQLearningAgent.predict (pkg/double_q_learning.py:119-124) for n packed states */
 int dql_agent_predict(int device, const double* qa, const double* qb, const int32_t* idx, int64_t n, uint8_t* action_out);
 /* DoubleQLearningAgent.update (pkg/double_q_learning.py:91-146) replayed strictly in order for n transitions:

@@ -206,6 +206,27 @@ def test_trainer_full_curriculum_hip_equals_oracle_engine(tmp_path, monkeypatch)
     assert np.array_equal(np.load(tmp_path / "hip" / "Q_table_a.npy"), np.load(tmp_path / "orc" / "Q_table_a.npy"))
 
 
+def test_trainer_restarts_and_steps_back_alike_on_hip_and_oracle_engines(tmp_path, monkeypatch):
+    """Round 5: level restarts (`restart_after`) and steps back (`step_back_after`) — table surgery between launches (counters cleared, slices transferred again, levels
+    entered a second time) — driven by the HIP engine and by the CPU oracle behind the same Trainer: same history (restart and step-back counts included), identical tables."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import dql_multirotor_landing_amd.trainer as T
+    from test_dist_gloo import _oracle_engine_class, _strip
+    kw = dict(curriculum_steps=3, n_envs=192, chunk_steps=16, checkpoint_every=10**9, max_num_episodes=1500, t_max=3, mode="paper", judge_envs=64,
+              successive_successful_episodes=20, success_rate=2.0, eps_floor=0.2, restart_after=1.5, step_back_after=1, max_step_backs=2, periods_per_launch=4)
+    hip = T.Trainer(save_path=tmp_path / "hip", **kw)
+    h_hip = _strip(hip.curriculum_training())
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    orc = T.Trainer(save_path=tmp_path / "orc", **kw)
+    h_orc = _strip(orc.curriculum_training())
+    assert h_hip == h_orc and [h["level"] for h in h_hip] == [0, 1, 2]
+    assert h_hip[2]["step_backs"] == 2 and h_hip[2]["restarts"] >= 1 and h_hip[1]["restarts"] >= 1
+    for a, b in zip(hip._engine.get_tables(), orc._engine.get_tables()):
+        assert np.array_equal(np.asarray(a).ravel(), np.asarray(b).ravel())
+
+
 def test_sharded_trainer_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     """The sharded Trainer under torch.distributed.run with 2 ranks (tests/_rehearsal_training.py: gloo stand-in communicator, both
     ranks on GPU 0 — the RCCL path needs one GPU per rank and is exercised by the driver's multi-GPU runs and, on one rank, by
@@ -396,3 +417,34 @@ def test_training_env_float32_keyword():
     with pytest.raises(ValueError):
         e32.step(0, 1)
     e64.close(); e32.close()
+
+
+def test_agent_update_is_deferred_and_every_access_sees_it_finished(golden_dir):
+    """ABI v6: `DoubleQLearningAgent.update` returns when its kernel is launched; the changed cell and its visit counter reach the public arrays at the next access
+    through the agent.  Whatever that access is — reading a table, replacing one, predict, another update, save, close — it sees the update done, and the
+    sequence of table values equals the reference's (golden G4: 300 sequential updates incl. the ignored uniform draw B1), checked after every single update."""
+    from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
+    g = np.load(golden_dir / "g4_agent.npz")
+    np.random.seed(42)
+    a = DoubleQLearningAgent(5)
+    for i in range(120):
+        sa = tuple(int(x) for x in g["upd_sa"][i])
+        a.update(sa, tuple(int(x) for x in g["upd_ns"][i]), g["upd_alpha"][i], 0.99, g["upd_reward"][i])
+        assert a._pending                                    # nothing has asked for the result yet
+        kind = i % 4
+        if kind == 0:
+            assert a.Q_table_a[sa] == g["upd_q_after"][i]    # a read through the agent
+        elif kind == 1:
+            a.predict(sa[:5]); assert a._qa[sa] == g["upd_q_after"][i]   # any call on the agent (the raw array is patched by then)
+        elif kind == 2:
+            held = a._qa; a.Q_table_b = np.zeros_like(a._qb); assert held[sa] == g["upd_q_after"][i]   # replacing a table finishes the update first
+        # kind 3: straight into the next update, which finishes this one before it launches
+        assert not a._pending or kind == 3
+    assert a.state_action_counter.sum() == 120 and not a.Q_table_b.any()
+    # two updates back to back, then close(): the arrays hold both
+    b = DoubleQLearningAgent(5)
+    b.update((0, 1, 1, 1, 3, 2), (0, 1, 1, 1, 3), 0.5, 0.99, 1.0)
+    b.update((0, 1, 1, 1, 3, 1), (0, 1, 1, 1, 3), 0.5, 0.99, 2.0)
+    qa = b._qa
+    b.close()
+    assert qa[0, 1, 1, 1, 3, 2] == 0.5 and qa[0, 1, 1, 1, 3, 1] == 1.0 + 0.5 * 0.99 * 0.0 and b._cnt.sum() == 2
