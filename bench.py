@@ -127,7 +127,7 @@ def cpu_baseline(envs: int, steps: int, dtype: int, cfg_kw: dict):
 # profiles/r5_level_series_seed8.jsonl: 0.888 +- 0.004 population success for 700 episodes per env — and every restart lands on another one.  12 seeds,
 # this kernel: all five levels by the rule in 6 seeds without restarts, in 10 with (profiles/r5_curriculum_restart_sweep.jsonl); the two that remain never see
 # a level-4 attempt above 0.94 and hand over the best attempt they saw when the budget runs out.
-CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 64, "periods_per_launch": 16, "eps_tail": 0.0, "eps_tail_after": 192, "population_gate": 0.94, "restart_after": 96, "step_back_after": 1}
+CURRICULUM_KW: dict = {"quirks": 0x60, "judge_envs": 64, "periods_per_launch": 16, "eps_tail": 0.0, "eps_tail_after": 192, "population_gate": 0.94, "restart_after": 96, "step_back_after": 3}
 CURRICULUM_BUDGET_PER_ENV = 768  # episodes per env and level before the next level starts anyway (the reference: 50 000 episodes of ONE env)
 CURRICULUM_SYNC = 16
 # tabular RL is seed-noisy (per seed: goal-hold 0.87-0.96, touchdown 0.70-0.95, profiles/r3_curriculum_p8_p16_judge_sweep.jsonl): twelve
@@ -189,7 +189,7 @@ def curriculum_leg(args, comm, world, rank, dev_index, dtype):
                 "level0_promoted_per_seed": [bool(r["levels"][0]["promoted"]) for r in runs],
                 "population_success_at_promotion": {"min": min(pops) if pops else None, "mean": sum(pops) / len(pops) if pops else None,
                                                     "note": "success rate of ALL envs' episodes over the chunks holding the most recent >= 100 episodes when the judged envs' deque passed 0.96 / 100"},
-                "rule": "deque(100) of the 64 judged envs' episodes in generation order > 0.96 (pkg/trainer.py:218-232) AND population success >= 0.94, or the level's episode budget exhausted (:187); a level above 0 not promoted after 96 episodes per env is started over from the level below (restart_after), a level above 1 that fails again goes back one level (step_back_after, at most 3 times)",
+                "rule": "deque(100) of the 64 judged envs' episodes in generation order > 0.96 (pkg/trainer.py:218-232) AND population success >= 0.94, or the level's episode budget exhausted (:187); a level above 0 not promoted after 96 episodes per env is started over from the level below (restart_after), a level above 1 that has failed 4 attempts in a row lets the level below be learnt again first (step_back_after = 3, at most 3 times per run, never cascading; a re-learning that is not promoted falls back to the tables the level was promoted with)",
                 "stage4_greedy_4096_episodes": {"trained_mean": {k: sum(r["stage4_greedy_4096_episodes"][k] for r in runs) / len(runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "trained_worst_seed": {k: min(r["stage4_greedy_4096_episodes"][k] for r in runs) for k in ("touchdown_rate", "goal_hold_rate")},
                                                 "reference_assets": greedy(ROOT / "tests" / "golden" / "assets")},

@@ -160,10 +160,12 @@ class Trainer:
         # env (profiles/r4_bench_default_detail.json).  A restart is a fresh draw of that early phase; the promotion rule itself is untouched.
         self._restart_after = None if restart_after is None else float(restart_after)
         # step_back_after (restarts; None = never): a level k >= 2 still not promoted after this many restarts is not restarted again — the trainer steps BACK one level:
-        # level k - 1 is started over from level k - 2 (transfer, cleared counters, the promotion rule as for any level) and level k after it.  Restarts redraw a level's
-        # fixed point from the SAME table of the level below; when every draw fails it is that table the level cannot be learnt from (12 seeds of the bench recipe: every
-        # level that is promoted at all needs at most 1 restart, the two seeds that fail level 4 fail it 8 times in a row, profiles/r5_bench_default_detail.json).
-        # At most `max_step_backs` per run (each costs at most two levels' budgets); the best attempt of a level survives its step-backs and is what a finally exhausted budget hands over.
+        # level k - 1 is learnt again from level k - 2 (transfer, cleared counters, the promotion rule as for any level) and level k after it.  Restarts redraw a level's
+        # fixed point from the SAME table of the level below; when every draw fails it is that table the level cannot be learnt from (48 seeds of the bench recipe: a level
+        # that is promoted at all needs at most 3 restarts, a level that fails fails all 8 attempts of its budget, profiles/r5_curriculum_48_seeds.jsonl).
+        # The level learnt again gets step_back_after + 1 restart windows, never steps back itself (no cascade), and when it is not promoted in them it falls back to the
+        # tables it WAS promoted with (the level above then goes on from those).  At most `max_step_backs` per run; the best attempt of a level survives its step-backs and
+        # is what a finally exhausted budget hands over.
         self._step_back_after = None if step_back_after is None else int(step_back_after)
         self._max_step_backs = int(max_step_backs)
         if self._step_back_after is not None and (self._step_back_after < 1 or self._restart_after is None):
@@ -491,6 +493,8 @@ class Trainer:
         k_next = first_level
         first_promotion_wall: Dict[int, float] = {}
         step_backs, best_of_level = 0, {}  # (step_back_after) steps back taken so far; best attempt of a level over its lineages
+        promoted_snap: Dict[int, Any] = {}  # level -> (tables, history entry) when the rule promoted it: what a failed re-learning of the level falls back to
+        relearning = None                   # the level being learnt again after a step back (it never steps back itself, and gets a short budget)
         while k_next < self._curriculum_steps:
             self._working_curriculum_step = k = k_next
             k_next = k + 1
@@ -526,7 +530,11 @@ class Trainer:
             best_attempt = best_of_level.get(k)  # (population success rate, tables) of the best attempt given up so far (not checkpointed: a resumed run starts collecting again)
             stalled = False
             info: Dict[str, Any] = {}
-            while episodes < self._max_num_episodes:
+            # a level learnt AGAIN after a step back gets (step_back_after + 1) restart windows, not the whole budget: it has been promoted from these tables before
+            level_budget = self._max_num_episodes
+            if relearning == k and not resumed:
+                level_budget = min(level_budget, int((self._step_back_after + 1) * self._restart_after * self._n_envs))
+            while episodes < level_budget:
                 sched_episode = int(episodes / self._eps_episode_scale)
                 eps = max(self.exploration_rate(sched_episode, k), self._eps_floor)  # scale 1, floor 0: the reference schedule
                 if self._eps_tail is not None and k == 0 and sched_episode >= 2000 and episodes >= self._eps_tail_after * self._n_envs:
@@ -564,12 +572,13 @@ class Trainer:
                 if done_level and self._population_gate is not None and rate < self._population_gate:
                     done_level = False  # the judged envs' window passed, the population has not arrived: the level goes on (the deque keeps sliding)
                 if (not done_level and self._restart_after is not None and k >= 1 and self._mode == "paper"
-                        and episodes - restart_base >= self._restart_after * self._n_envs and episodes < self._max_num_episodes):
+                        and episodes - restart_base >= self._restart_after * self._n_envs and episodes < level_budget):
                     # start the level over (see __init__): every rank does the same, at a chunk boundary = on synchronised tables
                     qa_, qb_, cnt = (np.asarray(t, dtype=np.float64).reshape(-1).copy() for t in eng.get_tables())
                     if best_attempt is None or rate > best_attempt[0]:  # the attempt given up may still be the best one the budget buys
                         best_attempt = (rate, qa_, qb_, cnt.copy())
-                    if (self._step_back_after is not None and k >= 2 and k - 1 >= first_level and restarts >= self._step_back_after and step_backs < self._max_step_backs):
+                    if (self._step_back_after is not None and k >= 2 and k - 1 >= first_level and restarts >= self._step_back_after and step_backs < self._max_step_backs
+                            and relearning is None):
                         stalled = True  # every redraw from this table of level k - 1 failed: step back instead of restarting again (see __init__)
                         break
                     per_level = cnt.size // 5
@@ -604,9 +613,10 @@ class Trainer:
                 while self.history and self.history[-1]["level"] >= k - 1:  # one entry per level: level k - 1's is written again when it ends again
                     self.history.pop()
                 self._progress = None
+                relearning = k - 1
                 k_next = k - 1
                 continue
-            exhausted = not promoted and episodes >= self._max_num_episodes
+            exhausted = not promoted and episodes >= level_budget
             if exhausted and best_attempt is not None and best_attempt[0] > (info.get("Success rate") or 0.0):
                 # the budget ran out in a later, worse attempt: the level hands over the tables of its best one (same rule as the reference's budget
                 # hand-over, pkg/trainer.py:187 — it just does not hand over a restart that had barely begun)
@@ -614,11 +624,24 @@ class Trainer:
                 info["Success rate"] = best_attempt[0]
             if promoted and k not in first_promotion_wall:
                 first_promotion_wall[k] = time.perf_counter() - t_start
-            self.history.append({"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "restarts": restarts, "step_backs": step_backs, "episodes": episodes,
-                                 "agent_periods": steps, "success_rate": info.get("Success rate"),
-                                 "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start,
-                                 # (with step backs a level can end more than once: when the rule FIRST promoted it — "stage k + 1 entered")
-                                 "wall_first_promoted_s": first_promotion_wall.get(k)})
+            fell_back = False
+            if relearning == k:
+                relearning = None
+                if not promoted and k in promoted_snap:
+                    # learnt again and not promoted within its short budget: the level keeps the tables (and the history entry) it WAS promoted with; the level
+                    # above goes on from those with plain restarts
+                    eng.set_tables(*promoted_snap[k][0])
+                    self.history.append(dict(promoted_snap[k][1], step_backs=step_backs, wall_since_start_s=time.perf_counter() - t_start))
+                    promoted, exhausted, fell_back = True, False, True
+            if not fell_back:
+                entry = {"level": k, "promoted": promoted, "exhausted": exhausted, "promoted_at": promoted_at, "restarts": restarts, "step_backs": step_backs, "episodes": episodes,
+                         "agent_periods": steps, "success_rate": info.get("Success rate"),
+                         "wall_s": time.perf_counter() - t_level, "wall_since_start_s": time.perf_counter() - t_start,
+                         # (with step backs a level can end more than once: when the rule FIRST promoted it — "stage k + 1 entered")
+                         "wall_first_promoted_s": first_promotion_wall.get(k)}
+                self.history.append(entry)
+                if promoted and self._step_back_after is not None:
+                    promoted_snap[k] = (tuple(np.asarray(t, dtype=np.float64).reshape(-1).copy() for t in eng.get_tables()), dict(entry))
             if self._mode == "reference":
                 # transfer AFTER finishing level k: Q[k] = Q[k-1] * ratio, k = 0 wraps (B6, pkg/trainer.py:237-243)
                 eng.transfer(k, self.transfer_learning_ratio(k))

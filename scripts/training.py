@@ -44,7 +44,7 @@ if __name__ == "__main__":
                     help="fly the world the reference's manager node RESOLVED under roslaunch (platform 1 m/s, observation noise 0.25 m / 0.1 m/s: config.AS_LAUNCHED, "
                          "golden G14) instead of the launch file's literal values (1.6 m/s, no noise)")
     ap.add_argument("--restart-after", type=float, default=None, help="a level above 0 not promoted after this many episodes per env is started over from the level below (default: never, the reference; --recipe bench: 96)")
-    ap.add_argument("--step-back-after", type=int, default=None, help="a level above 1 still not promoted after this many restarts goes back one level instead of restarting again (needs --restart-after; default: never; --recipe bench: 1)")
+    ap.add_argument("--step-back-after", type=int, default=None, help="a level above 1 still not promoted after this many restarts goes back one level instead of restarting again (needs --restart-after; default: never; --recipe bench: 3)")
     ap.add_argument("--population-gate", type=float, default=None, help="promotion also needs this success rate of ALL envs (default: the reference's deque alone; --recipe bench: 0.94)")
     a = ap.parse_args()
     import os
