@@ -428,3 +428,29 @@ def test_step_back_after_failed_restarts(tmp_path, monkeypatch):
     assert np.isfinite(a._engine.get_tables()[0]).all()
     with pytest.raises(ValueError, match="step_back_after"):
         T.Trainer(save_path=tmp_path / "c", step_back_after=1, **{**kw, "restart_after": None})
+
+
+def test_step_back_falls_back_to_the_promoted_tables_when_the_relearning_fails(tmp_path, monkeypatch):
+    """The level learnt again after a step back has a short budget, never steps back itself, and — when the rule does not promote it — the run goes on from the tables
+    the level WAS promoted with: its history entry stays the promoted one.  Scripted promotion window: levels 0 and 1 pass on their first attempt, nothing passes after."""
+    import dql_multirotor_landing_amd.trainer as T
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    real = T.PromotionWindow
+
+    class Scripted(real):
+        resets = 0
+        def reset(self):
+            Scripted.resets += 1
+            return super().reset()
+        def push_flags(self, flags):
+            super().push_flags(flags)
+            return 0 if Scripted.resets <= 3 and len(flags) else None   # resets 1 (constructor's level-0 start), 2 (level 0), 3 (level 1): see the asserts below
+    monkeypatch.setattr(T, "PromotionWindow", Scripted)
+    kw = dict(curriculum_steps=3, n_envs=48, chunk_steps=8, checkpoint_every=10**9, max_num_episodes=600, t_max=3, mode="paper", judge_envs=16,
+              successive_successful_episodes=10, eps_floor=0.3, restart_after=1.5, step_back_after=1, max_step_backs=2)
+    tr = T.Trainer(save_path=tmp_path / "a", **kw)
+    h = tr.curriculum_training()
+    assert [x["level"] for x in h] == [0, 1, 2]
+    assert h[0]["promoted"] and h[1]["promoted"] and not h[2]["promoted"] and h[2]["exhausted"]
+    assert h[2]["step_backs"] == 2 and h[1]["step_backs"] >= 1          # level 1 was learnt again (twice) and fell back to its promoted entry each time
+    assert h[1]["restarts"] == 0 and h[1]["wall_first_promoted_s"] is not None
