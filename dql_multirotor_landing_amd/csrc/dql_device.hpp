@@ -208,13 +208,17 @@ template <typename T> DQL_DEV T det_log(T x) {  // x in (0, 1], normal
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10
 // ---------------------------------------------------------------------------------------------
-DQL_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+// kv: the 10 + 10 round keys (k0 + r W0, k1 + r W1) held in registers by the caller, or null.  The key is a launch constant: left to itself the compiler hoists the
+// wave-uniform key schedule out of the period loop into 20 SGPRs, which the step kernel does not have — it spills them into VGPR lanes and restores one per
+// round at every call (v_readlane + a hazard s_nop + an SGPR-operand v_xor: 16 + 8 + 16 issue slots per call, two calls per period); as VGPRs filled once
+// per launch they cost the v_xor alone (k_step)
+DQL_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4], const uint32_t* kv = nullptr) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: integer multiplies are quarter rate
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    const uint32_t n0 = h1 ^ c1 ^ (kv ? kv[r] : k0), n2 = h0 ^ c3 ^ (kv ? kv[10 + r] : k1);
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
@@ -275,6 +279,7 @@ template <typename T> struct SimK {
 // loop state; as wave-uniform scalars they overflow the SGPR file and every use of a spilled one costs a v_readlane.  A VALU
 // operand may just as well be a VGPR: one v_mov per constant before the loop (opaque to the compiler, so it stays there).
 DQL_DEV float to_vgpr(float x) { float y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
+DQL_DEV uint32_t to_vgpr(uint32_t x) { uint32_t y; asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 template <typename T> struct HotK {
   T dt, g, inv_m, I[3], inv_I[3], l, h, kf, lkf, kmkf, aup, adn, omax, cd, crd;
   T dtm, dtg, dtI[3], oup, odn, nlcd, hdt, low_z;
@@ -912,7 +917,7 @@ template <typename T> DQL_DEV void manager_states(const T (&R)[9], T cy, T sy, T
 // pairs each, ~1 300 instructions per period) are never consumed and are not made.  Same values, bit for bit, as drawing every tick.
 template <typename T>
 DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_index, uint32_t k0, uint32_t k1,
-                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, bool with_noise = true, PlatRec<T>* rec = nullptr) {
+                         uint32_t step_lo, uint32_t step_hi, uint32_t env_id, uint32_t mgr_in_step, bool with_noise = true, PlatRec<T>* rec = nullptr, const uint32_t* kv = nullptr) {
   const T dxw = e.mp_x - e.p[0], dyw = e.mp_y - e.p[1];
   const T dvx = e.mp_u - e.v[0], dvy = e.mp_v - e.v[1];
   const T rpx = fma_(cy, dxw, sy * dyw), rpy = fma_(cy, dyw, -(sy * dxw));
@@ -920,7 +925,7 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
   T opx = rpx, opy = rpy, ovx = rvx, ovy = rvy;
   if (with_noise && s.noisy) {
     uint32_t r[4]; T n0, n1, n2, n3;
-    philox4x32(step_lo, step_hi, env_id, STREAM_NOISE0 + mgr_in_step, k0, k1, r);
+    philox4x32(step_lo, step_hi, env_id, STREAM_NOISE0 + mgr_in_step, k0, k1, r, kv);
     box_muller(r[0], r[1], n0, n1); box_muller(r[2], r[3], n2, n3);
     opx = fma_(s.noise_p, n0, opx); opy = fma_(s.noise_p, n1, opy); ovx = fma_(s.noise_v, n2, ovx); ovy = fma_(s.noise_v, n3, ovy);
   }
@@ -1208,17 +1213,17 @@ struct PeriodCtx {
 // (double_q_learning.py:110-117, mdp.py:543-560).  TabPtr: pointer to the (read-only) acting Q tables.
 template <typename T, typename TabPtr>
 DQL_DEV PeriodCtx period_begin(const SimK<T>& s, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr, int ext_action, uint64_t seed,
-                               uint32_t env_id, long long step_index) {
+                               uint32_t env_id, long long step_index, const uint32_t* kv = nullptr) {
   PeriodCtx c;
   c.k0 = (uint32_t)seed; c.k1 = (uint32_t)(seed >> 32); c.step_lo = (uint32_t)step_index; c.step_hi = (uint32_t)((uint64_t)step_index >> 32);
   uint32_t r[4];
-  philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION, c.k0, c.k1, r);
+  philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION, c.k0, c.k1, r, kv);
   c.is_reset = (e.flags & FL_DONE) != 0;
   c.prev_idx = e.idx_x; c.prev_idy = e.idx_y;
   const bool two = s.two_axis != 0;
   int action = 2, action_y = 2;
   uint32_t r2[4] = {0u, 0u, 0u, 0u};
-  if (two) philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION + 1u, c.k0, c.k1, r2);
+  if (two) philox4x32(c.step_lo, c.step_hi, env_id, STREAM_ACTION + 1u, c.k0, c.k1, r2, kv);
   if (c.is_reset) {
     e.step_count = 0; e.cur_check = 0; e.code = DQL_NON_TERMINAL; e.cum_x = T(0.0); e.cum_y = T(0.0);
     e.pitch_sp = T(0.0); e.roll_sp = T(0.0);
@@ -1417,10 +1422,19 @@ template <int TICK, typename T> struct TickConsts {
 // constant 0); X_RUNTIME: decided by s.two_axis (wave-uniform), both forms in the code — the layouts the host does not pick by itself.
 enum { X_TWO = 0, X_ONLY = 1, X_RUNTIME = 2 };
 template <int TICK, int XMODE, typename T, typename TabPtr>
-DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, const MdpRun<T>& mr, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr,
-                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long mgr0, int sched, unsigned prio_role = 0u) {
+DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc, const MdpK<T> DQL_CONST_AS* mp, const MdpRun<T>& mr, Env<T>& e, const QRow& qx, TabPtr qa, TabPtr qb, int mode, uint32_t eps_thr,
+                             int ext_action, uint64_t seed, uint32_t env_id, long long step_index, long long mgr0, int sched, unsigned prio_role = 0u, const uint32_t* kv = nullptr) {
+  SimK<T> s = s_in;
+#ifndef DQL_AB_NO_OPAQUE_FLAGS  // A/B builds (tools/ab_build.sh)
+  // Every wave-uniform condition on the run's mode, quirk bits, working level and placement rule is loop-invariant, so the compiler evaluates each ONCE before
+  // the period loop and keeps it as a 64-bit lane mask — a dozen SGPR pairs the kernel does not have: they were spilled into VGPR lanes and read back at every use
+  // (two v_readlane + a hazard wait each).  Made opaque here, once per period, the conditions are re-derived where they are used: a scalar compare each.
+  // (the packed layout — batches of at most one wave per SIMD — is indifferent: 4 096 envs +0.3 %, 32 768 / 65 536 -0.3 %: left alone)
+  if constexpr (sizeof(T) == 4 && (TICK == TICK_LIT || TICK == TICK_PLAIN))
+    asm volatile("" : "+s"(s.quirks), "+s"(s.working), "+s"(s.init_uniform), "+s"(mode));
+#endif
   DQL_SECTION("period_begin");
-  const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps_thr, ext_action, seed, env_id, step_index);
+  const PeriodCtx c = period_begin(s, e, qx, qa, qb, mode, eps_thr, ext_action, seed, env_id, step_index, kv);
   T B[9];
   DQL_SECTION("make_B");
   make_B(e.pitch_sp, e.roll_sp, B);
@@ -1451,7 +1465,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
     if ((((unsigned)mgr_index) ^ prio_role) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
 #endif
     manager_states(R, cy, sy, e.v[2], e.vz_state, e.yw_state);
-    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec);
+    manager_obs(s, e, cy, sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec, kv);
     ++mgr_in_step; ++mgr_index;
     DQL_PHASE(e, 3);
   };
@@ -1488,7 +1502,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s, const TickConsts<TICK, T>& tc, co
           float Rm[9];  // scoped: a long-lived array would be demoted to LDS by the compiler
           rot_to_array(rp, Rm);
           manager_states(Rm, rp.cy, rp.sy, e.v[2], e.vz_state, e.yw_state);
-          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec);
+          manager_obs(s, e, rp.cy, rp.sy, mgr_index, c.k0, c.k1, c.step_lo, c.step_hi, env_id, mgr_in_step, mgr_in_step == last_mgr, &prec, kv);
           ++mgr_in_step; ++mgr_index;
           DQL_PHASE(e, 3);
         }

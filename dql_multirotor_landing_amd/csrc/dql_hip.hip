@@ -373,6 +373,9 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
 #endif
   }
   long long dec_w = 0, don_w = 0, rfx_w = 0;  // per-wave totals over the periods of this launch (wave-uniform after the reductions)
+  // the reward total is an integer (fixed point): every lane keeps its own sum over the launch's periods (< 32 x 2^50) and the wave adds them up ONCE, behind the
+  // period loop — the 64-bit DPP reduction used to run in every period (45 instructions of each env wave's period)
+  long long rfx_lane = 0;
   // terminal histogram of the wave over the launch: one ballot per CheckResult code and period instead of one global atomic per finished
   // episode (thousands per period on a handful of addresses at large batches)
   unsigned code_w[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -384,6 +387,16 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
   if constexpr (sizeof(T) == 4 && BLOCK < 512) cfgk = period_consts_in_vgprs(cfgk);
 #endif
   const TickConsts<TICK, T> tc(cfgk);
+  // the Philox round keys (a launch constant) in VGPRs, where there are registers to spare (philox4x32)
+  uint32_t kv_[20];
+  const uint32_t* kv = nullptr;
+#ifndef DQL_AB_NO_VGPR_KEYS  // A/B builds (tools/ab_build.sh)
+  if constexpr (sizeof(T) == 4 && BLOCK < 512 && (TICK == TICK_LIT || TICK == TICK_PLAIN)) {  // (the VGPR-constant layouts have their registers spoken for: 112 SGPR spills with the keys against 47)
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { kv_[r] = to_vgpr((uint32_t)a.seed + (uint32_t)r * 0x9E3779B9u); kv_[10 + r] = to_vgpr((uint32_t)(a.seed >> 32) + (uint32_t)r * 0xBB67AE85u); }
+    kv = kv_;
+  }
+#endif
 #ifndef DQL_AB_NO_FAIR_PRIO
   // ROUND 5: the two waves of a SIMD take turns at the issue priority.  The arbiter serves priority first, then AGE: of two waves running the same
   // program the older one is nearly unimpeded and the younger gets the leftover slots — at exactly two waves per SIMD the older half of the env
@@ -424,7 +437,7 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
 #else
                                                           0u
 #endif
-                                                          );
+                                                          , kv);
       DQL_SECTION("accumulate");
       if (STAGED) {
         if (o.cell >= 0) { atomicAdd(&sT[o.cell], (unsigned long long)o.target_fx); atomicAdd(&sM[o.cell], 1u); }
@@ -447,7 +460,7 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
     }
 #endif
     // wave64 shuffle reductions -> per-wave totals
-    dec_w += __popcll(__ballot(dec != 0)); don_w += __popcll(__ballot(don != 0)); rfx_w += wave_sum(rfx);
+    dec_w += __popcll(__ballot(dec != 0)); don_w += __popcll(__ballot(don != 0)); rfx_lane += rfx;
 #ifdef DQL_PHASE_CLOCK
     if (i < a.n) DQL_PHASE(e, 5);
 #endif
@@ -464,6 +477,7 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
     clk1 = e.mark;
 #endif
   }
+  rfx_w = wave_sum(rfx_lane);
   dec = dec_w; don = don_w; rfx = rfx_w;
   if (STAGED) {
     if ((tid & 63) == 0) {
