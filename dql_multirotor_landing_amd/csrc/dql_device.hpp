@@ -345,7 +345,18 @@ struct LitM {
 #define DQL_X(n, v) static constexpr float n = v;
   DQL_REFM_SCALARS(DQL_X)
 #undef DQL_X
-#define DQL_L(n, a, b, c, d, e) static constexpr float n[5] = {a, b, c, d, e};
+#define DQL_L(n, a, b, c, d, e) static constexpr float n[5] = {a, b, c, d, e}; \
+  static DQL_DEV float at_##n(int k) { return k == 0 ? float(a) : k == 1 ? float(b) : k == 2 ? float(c) : k == 3 ? float(d) : float(e); } \
+  static DQL_DEV int level_##n(int nn, float value) { /* latest_valid_level on literal limits */ \
+    int res = nn - 1; \
+    if (4 < nn && (value < -float(e) || value > float(e))) res = 3; \
+    if (3 < nn && (value < -float(d) || value > float(d))) res = 2; \
+    if (2 < nn && (value < -float(c) || value > float(c))) res = 1; \
+    if (1 < nn && (value < -float(b) || value > float(b))) res = 0; \
+    return res; }
+  // at_<table>(k): the per-lane level lookup as a chain of selects between LITERALS.  (sel5 on the arrays — objects in constant memory once their address is
+  // taken — compiled to a divergent switch that picks the ADDRESS of element k, `s_getpc` + add + addc under an exec mask per case, and a global load from it:
+  // ~30 scalar instructions and a memory round trip per lookup, eight lookups per period)
   DQL_REFM_LIMITS(DQL_L)
   DQL_REFM_RATIOS(DQL_L)  // ratio_p / ratio_v[k] = lim[k + 1] / lim[k], divided on the build host (correctly rounded float32)
 #undef DQL_L
@@ -385,6 +396,13 @@ template <typename T> struct Env {
 template <typename T> DQL_DEV T sel5(const T (&a)[5], int k) {
   return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : k == 3 ? a[3] : a[4];
 }
+// the MDP's per-level tables at a lane's level k: from the constants buffer, or (LitM) as literal select chains
+template <typename M> DQL_DEV auto lim_p_at(const M& m, int k) { return sel5(m.lim_p, k); }
+template <typename M> DQL_DEV auto lim_v_at(const M& m, int k) { return sel5(m.lim_v, k); }
+template <typename M> DQL_DEV auto lim_a_at(const M& m, int k) { return sel5(m.lim_a, k); }
+DQL_DEV float lim_p_at(const LitM&, int k) { return LitM::at_lim_p(k); }
+DQL_DEV float lim_v_at(const LitM&, int k) { return LitM::at_lim_v(k); }
+DQL_DEV float lim_a_at(const LitM&, int k) { return LitM::at_lim_a(k); }
 
 // ---------------------------------------------------------------------------------------------
 // MDP  (pkg/mdp.py)
@@ -397,6 +415,12 @@ template <typename T> DQL_DEV int latest_valid_level(const T (&lim)[5], int n, T
   }
   return res;
 }
+template <typename M, typename T> DQL_DEV int level_p_of(const M& m, int n, T v) { return latest_valid_level(m.lim_p, n, v); }
+template <typename M, typename T> DQL_DEV int level_v_of(const M& m, int n, T v) { return latest_valid_level(m.lim_v, n, v); }
+template <typename M, typename T> DQL_DEV int level_a_of(const M& m, int n, T v) { return latest_valid_level(m.lim_a, n, v); }
+DQL_DEV int level_p_of(const LitM&, int n, float v) { return LitM::level_lim_p(n, v); }
+DQL_DEV int level_v_of(const LitM&, int n, float v) { return LitM::level_lim_v(n, v); }
+DQL_DEV int level_a_of(const LitM&, int n, float v) { return LitM::level_lim_a(n, v); }
 template <typename T> DQL_DEV int disc3(T v, T goal, T limit) {  // :160-170
   if (-limit <= v && v < -goal) return 0;
   if (-goal <= v && v <= goal) return 1;
@@ -415,13 +439,13 @@ template <bool BIN_GIVEN, typename M, typename T> DQL_DEV int discretise_impl(co
   const T cv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T ca = clip(norm_by(rel_a, m.a_max, m.inv_a_max), T(-1.0), T(1.0));
   const int n = m.working + 1;
-  int k = latest_valid_level(m.lim_p, n, cp);
-  const int kv = latest_valid_level(m.lim_v, n, cv), ka = latest_valid_level(m.lim_a, n, ca);
+  int k = level_p_of(m, n, cp);
+  const int kv = level_v_of(m, n, cv), ka = level_a_of(m, n, ca);
   k = kv < k ? kv : k;
   k = ka < k ? ka : k;
-  const T lp = sel5(m.lim_p, k), lv = sel5(m.lim_v, k), la = sel5(m.lim_a, k);
+  const T lp = lim_p_at(m, k), lv = lim_v_at(m, k), la = lim_a_at(m, k);
   T pc = m.beta, vc = m.beta, ac = m.sigma_a;
-  if constexpr (__is_same(M, LitM)) { if (k < m.working) { pc = sel5(m.ratio_p, k); vc = sel5(m.ratio_v, k); } }  // the same quotients, divided on the build host (tools/gen_refk.py)
+  if constexpr (__is_same(M, LitM)) { if (k < m.working) { pc = LitM::at_ratio_p(k); vc = LitM::at_ratio_v(k); } }  // the same quotients, divided on the build host (tools/gen_refk.py)
   else if (k < m.working) { pc = sel5(m.lim_p, k + 1) / lp; vc = sel5(m.lim_v, k + 1) / lv; }
   if (k == m.working) ac = ac * T(m.beta);
   const int dp = disc3(cp, lp * pc, lp);
@@ -497,7 +521,7 @@ DQL_DEV T mdp_reward(const M& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code,
   const T ncv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T npitch = norm_by(angle_sp, m.theta_max, m.inv_theta_max);
   const int k = idx_level(cur_idx);
-  const T lv = sel5(m.lim_v, k), la = sel5(m.lim_a, k);
+  const T lv = lim_v_at(m, k), la = lim_a_at(m, k);
   const T prev_p = shp_p, prev_v = shp_v, prev_a = shp_a;
   shp_p = m.w_p * abs_(ncp); shp_v = m.w_v * abs_(ncv); shp_a = m.w_theta * abs_(npitch);
   const T r_p_max = abs_(m.w_p) * lv * m.delta_t;
