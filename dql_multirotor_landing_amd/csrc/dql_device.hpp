@@ -167,6 +167,19 @@ template <typename T> DQL_DEV T det_atan(T x) {
 }
 template <typename T> DQL_DEV T det_atan2(T y, T x) {
   const T pi = T(3.14159265358979311600e+00), pio2 = T(1.57079632679489655800e+00);
+  if constexpr (sizeof(T) == 4) {
+    // the whole wave in front of the x axis with |y / x| below det_atan's first range bound (a yaw within 23.6 degrees: every flight that is not tumbling): the
+    // operations those lanes execute in the general path below — the quotient, det_atan's unreduced polynomial, the sign — in a straight line under ONE wave-uniform
+    // branch instead of five lane-divergent ones (an exec-mask save / restore and a skip branch each).  Bit-identical by construction; x == 0 lanes fail the test.
+    const T q = abs_(y / x);
+    if (__ballot(!(x > T(0.0) && q < T(0.4375))) == 0ull) {
+      const T z = q * q, w = z * z;
+      const T s1 = z * fma_(w, fma_(w, T(6.1687607318e-02), T(1.4253635705e-01)), T(3.3333328366e-01));
+      const T s2 = w * fma_(w, T(-1.0648017377e-01), T(-1.9999158382e-01));
+      const T a = q - q * (s1 + s2);
+      return y < T(0.0) ? -a : a;
+    }
+  }
   if (x == T(0.0)) {
     if (y == T(0.0)) return T(0.0);
     return y > T(0.0) ? pio2 : -pio2;
