@@ -1440,10 +1440,13 @@ template <typename T> struct TickUnroll { static constexpr int n = sizeof(T) == 
 // registers are free and every avoided v_readlane shortens the dependency-bound stream; at full occupancy it costs a wave).
 // TICK: 0 plain loop on SGPR constants, 1 per-tick constants in VGPRs + the loop laid out per manager period, 2 the same with the
 // packed float32 tick (physics_tick_pk), 3 plain loop with the reference vehicle's constants as literals (LitK)
-enum { TICK_PLAIN = 0, TICK_LONE = 1, TICK_PACKED = 2, TICK_LIT = 3 };
+// 4: the packed tick (2) with the reference MDP's constants as literals at the period's end (LitM) — what the host picks for small batches when the MDP is the reference's
+enum { TICK_PLAIN = 0, TICK_LONE = 1, TICK_PACKED = 2, TICK_LIT = 3, TICK_PACKED_LITM = 4 };
+constexpr bool tick_is_packed(int t) { return t == TICK_PACKED || t == TICK_PACKED_LITM; }
 template <int TICK, typename T> struct TickK { static DQL_DEV const SimK<T>& get(const SimK<T>& s) { return s; } };
 template <> struct TickK<TICK_LONE, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
 template <> struct TickK<TICK_PACKED, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
+template <> struct TickK<TICK_PACKED_LITM, float> { static DQL_DEV HotK<float> get(const SimK<float>& s) { return make_hot(s); } };
 template <> struct TickK<TICK_LIT, float> { static DQL_DEV LitK get(const SimK<float>& s) { return LitK{s.vz_sp, s.yw_sp}; } };
 // The tick constants in the form the layout wants them (SGPR struct, VGPR copies, literals) + the packed pairs: made ONCE per launch,
 // outside the loop over the launch's agent periods
@@ -1451,7 +1454,7 @@ template <int TICK, typename T> struct TickConsts {
   decltype(TickK<TICK, T>::get(*(const SimK<T>*)nullptr)) h;
   PkK pk;
   DQL_DEV explicit TickConsts(const SimK<T>& s) : h(TickK<TICK, T>::get(s)) {
-    if constexpr (sizeof(T) == 4 && TICK == TICK_PACKED) pk = make_pkk(h);
+    if constexpr (sizeof(T) == 4 && tick_is_packed(TICK)) pk = make_pkk(h);
   }
 };
 // XMODE: what the kernel knows about the config's axes at compile time.  X_TWO: a two-axis config (generic attitude law); X_ONLY: an x-axis config
@@ -1476,7 +1479,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
   DQL_SECTION("make_B");
   make_B(e.pitch_sp, e.roll_sp, B);
   DQL_SECTION("tick_setup");
-  constexpr bool HOT = TICK == TICK_LONE || TICK == TICK_PACKED;
+  constexpr bool HOT = TICK == TICK_LONE || tick_is_packed(TICK);
   const auto& h = tc.h;
   DQL_MARK_T(e, 3);
   DQL_PHASE(e, 1);
@@ -1519,7 +1522,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
     DQL_SECTION("platform_contact");
     platform_contact(h, e);
   };
-  if constexpr (sizeof(T) == 4 && TICK == TICK_PACKED) {
+  if constexpr (sizeof(T) == 4 && tick_is_packed(TICK)) {
     // float32: the packed tick (physics_tick_pk): the state the 500 Hz loop touches lives in register pairs for the whole period
     TickPk ts;
     pack_tick(e, ts);
@@ -1625,7 +1628,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
 #elif defined(DQL_AB_NO_LITERAL_MDP)
   const StepOut o = period_end<HOT ? MDP_VECTOR : MDP_SCALAR>(s, mp, mr, e, c, qa, qb, mode);
 #else
-  const StepOut o = period_end<TICK == TICK_LIT ? MDP_LITERAL : (HOT ? MDP_VECTOR : MDP_SCALAR)>(s, mp, mr, e, c, qa, qb, mode);
+  const StepOut o = period_end<(TICK == TICK_LIT || TICK == TICK_PACKED_LITM) ? MDP_LITERAL : (HOT ? MDP_VECTOR : MDP_SCALAR)>(s, mp, mr, e, c, qa, qb, mode);
 #endif
   DQL_MARK_T(e, 5);
   DQL_PHASE(e, 4);
