@@ -686,12 +686,12 @@ template <> struct YawIters<float> { static constexpr int n = 4; };
 template <> struct YawIters<double> { static constexpr int n = 5; };
 // float32 (FAST32): second-order start 1 + d/2 + 3 d^2 / 8, d = 1 - n2 (error 5 d^3 / 16), then THREE Newton steps (round 4: two left 2e-5 at a tilt
 // of 45 deg and 0.5 % at 60 deg; three are converged to rounding up to 60 deg)
-template <typename T> DQL_DEV T yaw_rnorm(T n2) {
+template <typename T> DQL_DEV T yaw_rnorm(T n2, T c375 = T(0.375)) {  // c375: the same 0.375 from a register of the caller's (agent_period)
   const T h = T(-0.5) * n2;
   T r;
   if constexpr (Fast32<T>::on) {
     const T d = T(1.0) - n2;
-    r = fma_(fma_(T(0.375), d, T(0.5)), d, T(1.0));
+    r = fma_(fma_(c375, d, T(0.5)), d, T(1.0));
 #pragma unroll
     for (int k = 0; k < 3; ++k) r = r * fma_(h * r, r, T(1.5));
   } else {
@@ -706,9 +706,9 @@ template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s) {
   c = R[0] * r; s = R[3] * r;
 }
 // the same + what the float32 attitude law builds the yaw-free attitude from: rn = 1 / cos(tilt), ct = cos(tilt) = n2 rn
-template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s, T& ct, T& rn) {
+template <typename T> DQL_DEV void yaw_cs(const T (&R)[9], T& c, T& s, T& ct, T& rn, T c375 = T(0.375)) {
   const T n2 = fma_(R[0], R[0], R[3] * R[3]);
-  rn = yaw_rnorm(n2);
+  rn = yaw_rnorm(n2, c375);
   c = R[0] * rn; s = R[3] * rn; ct = n2 * rn;
 }
 // attitude_controller.py:107-156
@@ -1481,6 +1481,16 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
   DQL_SECTION("tick_setup");
   constexpr bool HOT = TICK == TICK_LONE || tick_is_packed(TICK);
   const auto& h = tc.h;
+  // The literal layout's constants are instruction literals — which gfx9's three-operand encodings (v_med3, v_fma with an inline constant) cannot carry: for the yaw
+  // PID's clamp bounds and the yaw frame's 0.375 the compiler emitted an s_mov of the literal in front of EVERY use, three scalar instructions per physics tick.
+  // Pinned to SGPRs here (opaque: nothing to rematerialise) they stay scalar operands — in VGPRs they cost more than the s_movs (three VGPR sources per v_med3).
+  T yw_lo = T(h.yw_lo), yw_hi = T(h.yw_hi), yw_wind = T(h.yw_wind), c375 = T(0.375);
+#ifndef DQL_AB_NO_TICK_SREGS  // A/B builds (tools/ab_build.sh)
+  if constexpr (sizeof(T) == 4 && TICK == TICK_LIT) {
+    asm volatile("" : "+s"(yw_wind), "+s"(yw_hi), "+s"(c375));
+    if (T(h.yw_lo) == -T(h.yw_hi)) yw_lo = -yw_hi;
+  }
+#endif
   DQL_MARK_T(e, 3);
   DQL_PHASE(e, 1);
   T R[9], cy, sy, ct = T(1.0), rn = T(1.0);
@@ -1512,7 +1522,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
   auto control_and_plant = [&]() {
     DQL_SECTION("pid");
     const T thrust = pid_output(h, h.vz_kp, h.vz_ki, h.vz_lo, h.vz_hi, h.vz_wind, h.vz_sp, e.vz_state, e.vz_i, e.vz_x1, e.vz_x2, e.vz_y1, e.vz_y2, e.vz_y3);
-    const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, h.yw_lo, h.yw_hi, h.yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
+    const T r_cmd = pid_output(h, h.yw_kp, h.yw_ki, yw_lo, yw_hi, yw_wind, h.yw_sp, e.yw_state, e.yw_i, e.yw_x1, e.yw_x2, e.yw_y1, e.yw_y2, e.yw_y3);
     T cmd[4];
     DQL_SECTION("attitude");
     attitude(h, R, e.w, B, cy, sy, ct, rn, r_cmd, thrust, cmd, XMODE == X_ONLY || (XMODE == X_RUNTIME && s.two_axis == 0));
@@ -1580,12 +1590,15 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
     unpack_tick(ts, e);
   } else if constexpr (!(HOT && sizeof(T) == 4)) {
     // big batches (several waves per SIMD, registers decide the occupancy): the plain loop
+    // (physics ticks to go until the next manager tick, counted down: a compare + branch per tick; the phase counted up and wrapped cost an add, a compare,
+    //  a select and the compare + branch)
+    int togo = phase == 0 ? 0 : s.div - phase;
 #pragma unroll TickUnroll<T>::n
     for (int i = 0; i < n_ticks; ++i) {
       DQL_SECTION("rot");
-      quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn);
-      if (phase == 0) manager_tick();
-      phase = (phase + 1 == s.div) ? 0 : phase + 1;
+      quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn, c375);
+      if (togo == 0) { manager_tick(); togo = s.div; }
+      --togo;
       control_and_plant();
     }
   } else {
