@@ -795,8 +795,15 @@ template <bool PRE_CLIPPED = false, typename T, typename K> DQL_DEV void rotor_f
       const T d = ref - e.om[i];
       // (round 5 tried max(fma(oup, d, om), fma(odn, d, om)) — the same value bit for bit since 0 < odn < oup, one instruction less and one instead of two in
       // the four-cycle class: 19.20 vs 19.18 us per period, nothing: the tick sits within 7 % of its issue cost and 1 % is the noise of code placement)
+#ifdef DQL_AB_ROTOR_SELECT  // A/B builds (tools/ab_build.sh): the compare + select form
       const T c = d > T(0.0) ? T(s.oup) : T(s.odn);
       e.om[i] = fma_(c, d, e.om[i]);
+#else
+      // the larger of the two candidates IS the selected one (0 < odn < oup: oup d > odn d for d > 0, < for d < 0, equal at 0): two fmas and a max — one
+      // instruction of the four-cycle class per rotor instead of two (compare + select), bit for bit the same value
+      const T up = fma_(T(s.oup), d, e.om[i]), dn = fma_(T(s.odn), d, e.om[i]);
+      if constexpr (sizeof(T) == 4) e.om[i] = __builtin_fmaxf(up, dn); else e.om[i] = up > dn ? up : dn;
+#endif
     } else {
       const T a = ref > e.om[i] ? s.aup : s.adn;
       e.om[i] = fma_(a, e.om[i], (T(1.0) - a) * ref);
