@@ -404,6 +404,9 @@ template <typename T> struct Env {
   T shpy_p, shpy_v, shpy_a, cum_y;
   T reward, obs_px, obs_vx, obs_ax, obs_py, obs_vy, obs_ay;
   int idx_x, idx_y, step_count, cur_check, code, flags, action;
+  // level and position bin of idx_x / idx_y (registers only: unpacked once per launch by load_env, carried from period to period by period_end_with — the
+  // period's end used to unpack them from the packed indices it had just packed, ~30 integer instructions of the four-cycle class per period)
+  int bin_k, bin_p, bin_ky, bin_py;
 };
 
 template <typename T> DQL_DEV T sel5(const T (&a)[5], int k) {
@@ -447,7 +450,8 @@ template <typename T> DQL_DEV T norm_by(T x, T d, T inv) {
   else return x / d;
 }
 // M: MdpK<T> (run-time constants) or LitM (the reference MDP as literals, float32); BIN_GIVEN: the angle's grid bin is passed in (angle_bin_from_tangent)
-template <bool BIN_GIVEN, typename M, typename T> DQL_DEV int discretise_impl(const M& m, T rel_p, T rel_v, T rel_a, T angle, int angle_bin) {  // :257-333
+struct Bins { int k, p, v; };  // level, position bin, velocity bin: what a packed state index holds besides the acceleration and angle bins
+template <bool BIN_GIVEN, typename M, typename T> DQL_DEV int discretise_impl(const M& m, T rel_p, T rel_v, T rel_a, T angle, int angle_bin, Bins* bins = nullptr) {  // :257-333
   const T cp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
   const T cv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T ca = clip(norm_by(rel_a, m.a_max, m.inv_a_max), T(-1.0), T(1.0));
@@ -473,6 +477,7 @@ template <bool BIN_GIVEN, typename M, typename T> DQL_DEV int discretise_impl(co
 #pragma unroll
     for (int i = 1; i < 7; ++i) { const T d = abs_(T(m.angles[i]) - ct); if (d < bd) { bd = d; best = i; } }
   }
+  if (bins) *bins = Bins{k, dp, dv};
   return (((k * 3 + dp) * 3 + dv) * 3 + da) * 7 + best;
 }
 template <typename M, typename T> DQL_DEV int discretise(const M& m, T rel_p, T rel_v, T rel_a, T angle) { return discretise_impl<false>(m, rel_p, rel_v, rel_a, angle, 0); }
@@ -502,12 +507,17 @@ template <typename T, typename K> DQL_DEV T continuous_action(const K& m, T sp, 
 }
 template <typename M, typename T>
 DQL_DEV int mdp_check(const M& m, int& step_count, int& cur_check, int code, int prev_idx, int cur_idx, bool contact, T rel_p_x,
-                      T rel_p_y, T abs_p_z, bool two = false, int prev_idy = -1, int cur_idy = -1) {  // :335-439
+                      T rel_p_y, T abs_p_z, bool two = false, int prev_idy = -1, int cur_idy = -1,
+                      const Bins* cb = nullptr, int prev_k = 0, const Bins* cby = nullptr, int prev_ky = 0) {  // :335-439
+  // (cb / cby + prev_k / prev_ky: the bins of the current indices and the levels of the previous ones when the caller has them unpacked; else from the indices)
+  const Bins cx = cb ? *cb : Bins{idx_level(cur_idx), idx_pos(cur_idx), idx_vel(cur_idx)};
+  const Bins cyb = cby ? *cby : Bins{idx_level(cur_idy), idx_pos(cur_idy), idx_vel(cur_idy)};
+  const int pkx = cb ? prev_k : idx_level(prev_idx), pky = cby ? prev_ky : idx_level(prev_idy);
   // two-axis configs (beyond the reference, B16): the goal state is the joint goal of both 1-D MDPs
-  const bool goal_x = prev_idx >= 0 && idx_pos(cur_idx) == 1 && idx_vel(cur_idx) == 1;
-  const bool goal_y = !two || (prev_idy >= 0 && idx_pos(cur_idy) == 1 && idx_vel(cur_idy) == 1);
-  const bool lvl_x = idx_level(prev_idx) == m.working && idx_level(cur_idx) == m.working;
-  const bool lvl_y = !two || (idx_level(prev_idy) == m.working && idx_level(cur_idy) == m.working);
+  const bool goal_x = prev_idx >= 0 && cx.p == 1 && cx.v == 1;
+  const bool goal_y = !two || (prev_idy >= 0 && cyb.p == 1 && cyb.v == 1);
+  const bool lvl_x = pkx == m.working && cx.k == m.working;
+  const bool lvl_y = !two || (pky == m.working && cyb.k == m.working);
   step_count += 1;
   if (!(m.quirks & DQL_Q_STICKY_CHECK)) code = DQL_NON_TERMINAL;
   if (contact) code = DQL_TERMINAL_CONTACT;
@@ -529,11 +539,11 @@ DQL_DEV int mdp_check(const M& m, int& step_count, int& cur_check, int code, int
   return code;
 }
 template <typename M, typename T>
-DQL_DEV T mdp_reward(const M& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp) {  // :441-541
+DQL_DEV T mdp_reward(const M& m, T& shp_p, T& shp_v, T& shp_a, T& cum, int code, int cur_idx, T rel_p, T rel_v, T angle_sp, const Bins* cb = nullptr) {  // :441-541
   const T ncp = clip(norm_by(rel_p, m.p_max, m.inv_p_max), T(-1.0), T(1.0));
   const T ncv = clip(norm_by(rel_v, m.v_max, m.inv_v_max), T(-1.0), T(1.0));
   const T npitch = norm_by(angle_sp, m.theta_max, m.inv_theta_max);
-  const int k = idx_level(cur_idx);
+  const int k = cb ? cb->k : idx_level(cur_idx);
   const T lv = lim_v_at(m, k), la = lim_a_at(m, k);
   const T prev_p = shp_p, prev_v = shp_v, prev_a = shp_a;
   shp_p = m.w_p * abs_(ncp); shp_v = m.w_v * abs_(ncv); shp_a = m.w_theta * abs_(npitch);
@@ -1340,6 +1350,7 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
   DQL_SECTION("end_pitch");
   quat_to_R(e.q, R);
   int idx, idy = -1;
+  Bins bnx{0, 0, 0}, bny{0, 0, 0};
 #ifdef DQL_AB_NO_TANBIN  // A/B builds (tools/ab_build.sh): timing only, no parity
   constexpr bool TANBIN = false;
 #else
@@ -1348,21 +1359,23 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
   if constexpr (TANBIN) {  // the angle bins straight from the rotation matrix (angle_bin_from_tangent): pitch = atan2(-R20, sqrt(R00^2 + R10^2)), roll = atan2(R21, R22)
     const int bin_x = angle_bin_from_tangent(m, -R[6], fma_(R[0], R[0], R[3] * R[3]), true);
     DQL_SECTION("end_discretise");
-    idx = discretise_impl<true>(m, e.obs_px, e.obs_vx, e.obs_ax, T(0.0), bin_x);
-    if (two) idy = discretise_impl<true>(m, e.obs_py, e.obs_vy, e.obs_ay, T(0.0), angle_bin_from_tangent(m, -R[7], R[8] * R[8], R[8] > T(0.0)));
+    idx = discretise_impl<true>(m, e.obs_px, e.obs_vx, e.obs_ax, T(0.0), bin_x, &bnx);
+    if (two) idy = discretise_impl<true>(m, e.obs_py, e.obs_vy, e.obs_ay, T(0.0), angle_bin_from_tangent(m, -R[7], R[8] * R[8], R[8] > T(0.0)), &bny);
   } else {
     const T cyy = sqrt_(fma_(R[0], R[0], R[3] * R[3]));
     const T pitch = det_atan2(-R[6], cyy);
     DQL_SECTION("end_discretise");
-    idx = discretise(m, e.obs_px, e.obs_vx, e.obs_ax, pitch);
-    if (two) { const T roll = det_atan2(R[7], R[8]); idy = discretise(m, e.obs_py, e.obs_vy, e.obs_ay, -roll); }
+    idx = discretise_impl<false>(m, e.obs_px, e.obs_vx, e.obs_ax, pitch, 0, &bnx);
+    if (two) { const T roll = det_atan2(R[7], R[8]); idy = discretise_impl<false>(m, e.obs_py, e.obs_vy, e.obs_ay, -roll, 0, &bny); }
   }
-  if (idx < 0) idx = 0;
+  if (idx < 0) { idx = 0; bnx = Bins{0, 0, 0}; }
   e.idx_x = idx;
   if (two) {
-    if (idy < 0) idy = 0;
+    if (idy < 0) { idy = 0; bny = Bins{0, 0, 0}; }
     e.idx_y = idy;
   }
+  const int prev_k = e.bin_k, prev_p = e.bin_p, prev_ky = e.bin_ky, prev_py = e.bin_py;  // of prev_idx / prev_idy
+  e.bin_k = bnx.k; e.bin_p = bnx.p; e.bin_ky = bny.k; e.bin_py = bny.p;
   e.reward = T(0.0);
   // both tables' row of the new state, requested as soon as the index exists: check / reward below run while it travels, the TD target
   // takes it from registers, and so does the NEXT period's greedy choice when the env stays in registers (periods_per_launch > 1)
@@ -1372,11 +1385,11 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
   if (c.is_reset) return out;
   DQL_SECTION("end_check");
   const bool contact = (e.flags & FL_OBS_CONTACT) != 0;
-  e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy);
+  e.code = mdp_check(m, e.step_count, e.cur_check, e.code, prev_idx, idx, contact, e.obs_px, e.obs_py, e.p[2], two, prev_idy, idy, &bnx, prev_k, &bny, prev_ky);
   DQL_SECTION("end_reward");
-  const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp);
+  const T rew = mdp_reward(m, e.shp_p, e.shp_v, e.shp_a, e.cum_x, e.code, idx, e.obs_px, e.obs_vx, e.pitch_sp, &bnx);
   T rew_y = T(0.0);
-  if (two) rew_y = mdp_reward(m, e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y, e.code, idy, e.obs_py, e.obs_vy, -e.roll_sp);
+  if (two) rew_y = mdp_reward(m, e.shpy_p, e.shpy_v, e.shpy_a, e.cum_y, e.code, idy, e.obs_py, e.obs_vy, -e.roll_sp, &bny);
   e.reward = two ? rew + rew_y : rew;
   DQL_MARK_T(e, 42);
   DQL_SECTION("end_target");
@@ -1401,7 +1414,7 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
       const int b = argmax3(s0, s1, s2);
       const double boot = b == 0 ? v0 : (b == 1 ? v1 : v2);
       int mask;
-      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = idx_pos(prev_idx) != idx_pos(idx);
+      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask = prev_p != bnx.p;
       else mask = !done;
       const double target = (double)rew + (m.gamma * boot) * (double)mask;
       out.cell = prev_idx * 3 + c.action + (sel_b ? DQL_N_CELLS : 0);
@@ -1419,7 +1432,7 @@ DQL_DEV StepOut period_end_with(const SimK<T>& s, const M& m, Env<T>& e, const P
       const int by = argmax3(s0, s1, s2);
       const double boot_y = by == 0 ? v0 : (by == 1 ? v1 : v2);
       int mask_y;
-      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = idx_pos(prev_idy) != idx_pos(idy);
+      if (s.quirks & DQL_Q_BOOTSTRAP_ON_POS_CHANGE) mask_y = prev_py != bny.p;
       else mask_y = !done;
       const double target_y = (double)rew_y + (m.gamma * boot_y) * (double)mask_y;
       out.cell_y = prev_idy * 3 + c.action_y + (sel_b ? DQL_N_CELLS : 0);
@@ -1683,6 +1696,7 @@ template <typename T> DQL_DEV void load_env(Env<T>& e, const Quad<T>* __restrict
   if (c.per_env_platform) { const Quad<T> q13 = sr[13 * n + i]; e.mp_r = q13.a; e.mp_w = q13.b; }
   else { e.mp_r = c.mp_r; e.mp_w = c.mp_w; }
   e.idx_x = iv.x; e.idx_y = iv.y; e.step_count = iv.z & 0xffff; e.cur_check = (iv.z >> 16) & 0xffff;
+  e.bin_k = idx_level(iv.x); e.bin_p = idx_pos(iv.x); e.bin_ky = idx_level(iv.y); e.bin_py = idx_pos(iv.y);
   e.code = iv.w & 0xff; e.flags = (iv.w >> 8) & 0xff; e.action = (iv.w >> 16) & 0xff;
   e.reward = T(0.0); e.obs_px = e.obs_vx = e.obs_ax = e.obs_py = e.obs_vy = e.obs_ay = T(0.0);
 }
