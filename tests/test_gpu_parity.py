@@ -76,6 +76,8 @@ def test_long_run_with_episode_ends(mods):
     dict(block=256), dict(block=128),
     dict(two_axis=1), dict(two_axis=1, working_curriculum_step=3, init_uniform=1), dict(two_axis=1, quirks=Q_PAPER, trajectory=TRAJ_EIGHT),
     dict(two_axis=1, goal_logic=0, vz_setpoint=-0.4, working_curriculum_step=4, init_uniform=1),
+    # MDP constants that are NOT the reference's: the literal-table layouts (LitM) must not be selected — the constants buffer serves (round 5: dql_create's refm_matches)
+    dict(p_max=4.0, init_sigma=4.0 / 3), dict(f_ag=20.0, working_curriculum_step=1), dict(p_max=5.0, init_sigma=5.0 / 3, two_axis=1, block=256),
 ])
 def test_config_variants_bit_exact(mods, kw):
     Engine, Oracle = mods
