@@ -14,32 +14,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
 def evaluate(tables_dir, n_envs=4096, level=4, max_steps=600, seed=123, dtype=None, flavour="simulation", device=0, **cfg_kw):
-    """Greedy roll-outs; returns the terminal histogram of the FIRST episode of every env."""
-    import numpy as np
-    from dql_multirotor_landing_amd.config import CHECK_NAMES, F32, simulation_config, training_config
+    """Greedy roll-outs of the tables saved in `tables_dir`; returns the terminal histogram of the FIRST episode of every env."""
     from dql_multirotor_landing_amd.double_q_learning import DoubleQLearningAgent
-    from dql_multirotor_landing_amd.engine import Engine
+    from dql_multirotor_landing_amd.evaluation import first_episode_outcomes
     agent = DoubleQLearningAgent.load(Path(tables_dir))
-    dtype = F32 if dtype is None else dtype
-    if flavour == "simulation":
-        cfg = simulation_config(working_curriculum_step=level, dtype=dtype, **cfg_kw)
-    else:
-        cfg = training_config(level, dtype=dtype, **cfg_kw)
-    eng = Engine(cfg, n_envs, seed=seed, device=device)
-    eng.set_tables(*agent._padded())
-    first_code = np.full(n_envs, -1, dtype=np.int64)
-    eng.eval_steps(1)  # reset period
-    for _ in range(max_steps):
-        eng.eval_steps(1)
-        d, c = eng.dones()
-        new = (d != 0) & (first_code < 0)
-        first_code[new] = c[new]
-        if (first_code >= 0).all():
-            break
-    hist = {CHECK_NAMES[k]: int((first_code == k).sum()) for k in range(len(CHECK_NAMES))}
-    hist["unfinished"] = int((first_code < 0).sum())
-    eng.close()
-    return hist
+    return first_episode_outcomes(agent._padded(), n_envs, level, max_steps, seed, dtype, flavour, device, **cfg_kw)
 
 
 if __name__ == "__main__":

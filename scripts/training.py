@@ -46,6 +46,10 @@ if __name__ == "__main__":
     ap.add_argument("--restart-after", type=float, default=None, help="a level above 0 not promoted after this many episodes per env is started over from the level below (default: never, the reference; --recipe bench: 96)")
     ap.add_argument("--step-back-after", type=int, default=None, help="a level above 1 still not promoted after this many restarts goes back one level instead of restarting again (needs --restart-after; default: never; --recipe bench: 3)")
     ap.add_argument("--population-gate", type=float, default=None, help="promotion also needs this success rate of ALL envs (default: the reference's deque alone; --recipe bench: 0.94)")
+    ap.add_argument("--attempts", type=int, default=1, help="whole curricula to train (seed + 7919 j) until one has every level promoted by the rule and lands >= --accept-touchdown of 4 096 greedy "
+                                                          "episodes (dql_multirotor_landing_amd/attempts.py); none accepted: the best seen is kept.  1 (default): one run, the reference's situation; bench.py: 6")
+    ap.add_argument("--accept-touchdown", type=float, default=0.875, help="default: what the reference's own stage-4 tables land in such a batch")
+    ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args()
     import os
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -69,12 +73,32 @@ if __name__ == "__main__":
         extra["restart_after"] = a.restart_after
     if a.step_back_after is not None:
         extra["step_back_after"] = a.step_back_after
-    tr = Trainer(n_envs=a.envs, mode=a.mode, save_path=a.out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local if world > 1 else None,
-                 promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
-                 successive_successful_episodes=a.window,
-                 max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate, **extra)
-    hist = tr.curriculum_training()
+    from dql_multirotor_landing_amd.attempts import SELECTION_SEED, attempt_seed, curriculum_attempts
+    from dql_multirotor_landing_amd.comm import RcclComm
+    comm = RcclComm.from_env(local) if world > 1 else None  # ONE communicator for every attempt
+
+    def make_trainer(j):
+        out = a.out if (a.attempts == 1 or a.out is None) else f"{a.out}/attempt{j}"
+        return Trainer(n_envs=a.envs, mode=a.mode, save_path=out, dtype=F32 if a.dtype == "f32" else F64, chunk_steps=a.chunk, device=local if world > 1 else None,
+                       promotion_rule=a.promotion_rule, sync_period=a.sync_period, curriculum_steps=a.levels, t_max=a.t_max, judge_envs=a.judge_envs,
+                       successive_successful_episodes=a.window, seed=attempt_seed(a.seed, j), comm=comm,
+                       max_steps_per_level=a.max_steps_per_level, max_num_episodes=a.max_episodes, quiet=not a.verbose, fold_per_step=a.fold_per_step, eps_floor=a.eps_floor, success_rate=a.success_rate, **extra)
+
+    if a.attempts == 1:
+        tr = make_trainer(0)
+        hist = tr.curriculum_training()
+        out = {"history": hist, "save_path": str(tr._save_path), "world": world}
+    else:
+        from dql_multirotor_landing_amd.config import Q_PAPER, Q_REFERENCE
+        from dql_multirotor_landing_amd.evaluation import landing_score
+
+        def score(t):
+            q = Q_PAPER if a.mode == "paper" else Q_REFERENCE  # (the worlds scripts/simulation.py --mode flies)
+            return landing_score(t._double_q_learning_agent._padded(), 4096, a.levels - 1, seed=SELECTION_SEED, device=t._device, quirks=q)
+        res = curriculum_attempts(make_trainer, score, max_attempts=a.attempts, accept_touchdown=a.accept_touchdown, comm=comm, rank=rank)
+        tr, hist = res["trainer"], res["history"]
+        out = {"history": hist, "save_path": str(tr._save_path), "world": world, "chosen_attempt": res["chosen"], "accepted": res["accepted"], "attempts": res["attempts"]}
     if rank == 0:
-        print(json.dumps({"history": hist, "save_path": str(tr._save_path), "world": world}, indent=1))
+        print(json.dumps(out, indent=1))
     if tr._comm is not None:
         tr._comm.barrier()

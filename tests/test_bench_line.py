@@ -31,7 +31,10 @@ def synthetic_record(n_seeds=12, n_gpus=1):
            "promoted_levels_per_seed": [5] * n_seeds, "level0_promoted_per_seed": [True] * n_seeds,
            "population_success_at_promotion": {"min": 0.95, "mean": 0.96, "note": "n" * 200}, "rule": "r" * 150,
            "stage4_greedy_4096_episodes": {"trained_mean": {"touchdown_rate": 0.87, "goal_hold_rate": 0.94}, "trained_worst_seed": {"touchdown_rate": 0.83, "goal_hold_rate": 0.9},
-                                           "reference_assets": {"touchdown_rate": 0.8757, "goal_hold_rate": 0.954}}, "runs": runs}
+                                           "reference_assets": {"touchdown_rate": 0.8757, "goal_hold_rate": 0.954}},
+           "attempts": {"max": 6, "accept_touchdown": 0.875, "per_seed": [1 + s % 3 for s in range(n_seeds)], "accepted_per_seed": [True] * n_seeds, "selection": "t" * 300,
+                        "first_attempt": {"promoted_levels_per_seed": [5] * (n_seeds - 1) + [4], "trained_mean": {"touchdown_rate": 0.877, "goal_hold_rate": 0.949},
+                                          "trained_worst_seed": {"touchdown_rate": 0.824, "goal_hold_rate": 0.935}}}, "runs": runs}
     full = {"metric": "env-steps/sec (whole node)", "value": 5.2e9 * n_gpus, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": 2000, "warmup": 200, "preroll_steps": 512,
             "ms_per_step": 0.0247, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[4] share: " + "s" * 300, "workload_long": "l" * 600, "baseline_config": 4, "envs_per_gpu": 131072, "global_envs": 131072 * n_gpus,
@@ -77,6 +80,9 @@ def test_line_is_compact_and_round_trips():
         assert rec["curriculum"]["seeds_reaching_stage4_by_rule"] == n_seeds - 1 and rec["curriculum"]["wall_to_stage4_by_rule_s"] == 1.41
         assert rec["curriculum"]["promoted_levels_per_seed"] == [5] * n_seeds and "runs" not in rec["curriculum"]
         assert rec["curriculum"]["population_success_at_promotion"] == {"min": 0.95, "mean": 0.96}
+        att = rec["curriculum"]["attempts"]   # several whole curricula per seed: what was needed, and the first attempts beside the chosen ones
+        assert att["max"] == 6 and att["accept_touchdown"] == 0.875 and len(att["per_seed"]) == n_seeds and "selection" not in att
+        assert att["first_attempt"]["trained_worst_seed"]["touchdown_rate"] == 0.824 and att["first_attempt"]["promoted_levels_per_seed"][-1] == 4
         assert rec["detail_file"] == bench.DETAIL_FILE
         if n_gpus == 1:
             assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"])
