@@ -258,6 +258,49 @@ def test_sharded_trainer_two_ranks_on_one_gpu_equals_single_process(tmp_path):
         assert np.array_equal(np.load(tmp_path / "two" / f), np.load(tmp_path / "one" / f))
 
 
+def test_attempts_with_two_ranks_on_one_gpu_choose_what_one_process_chooses(tmp_path):
+    """Several whole curricula (attempts.py) under torch.distributed.run with 2 ranks: rank 0 alone flies the selection batch, both ranks take the same decision
+    (asserted inside the helper), and the attempts — seeds, histories, selection scores, chosen index, chosen tables — are those of one process running all envs."""
+    import json, os, socket, subprocess, sys
+    from pathlib import Path
+    import dql_multirotor_landing_amd.trainer as T
+    from dql_multirotor_landing_amd.attempts import SELECTION_SEED, attempt_seed, curriculum_attempts
+    from dql_multirotor_landing_amd.evaluation import landing_score
+    root = Path(__file__).resolve().parent.parent
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    args = ["--envs", "600", "--mode", "paper", "--chunk", "16", "--sync-period", "2", "--max-episodes", "700", "--levels", "3", "--t-max", "4",
+            "--window", "20", "--success-rate", "0.2", "--judge-envs", "400", "--attempts", "3", "--accept-touchdown", "0.0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def two_ranks(tag, accept):
+        a = list(args); a[-1] = str(accept)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), str(root / "tests" / "_rehearsal_training.py"), "--out", str(tmp_path / tag), *a],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout[r.stdout.index("{"):])
+
+    def one_process(tag, accept):
+        def make(j):
+            return T.Trainer(n_envs=600, mode="paper", chunk_steps=16, sync_period=2, max_num_episodes=700, curriculum_steps=3, t_max=4, successive_successful_episodes=20,
+                             success_rate=0.2, judge_envs=400, save_path=tmp_path / tag / f"attempt{j}", checkpoint_every=50, seed=attempt_seed(42, j))
+        return curriculum_attempts(make, lambda t: landing_score(t._double_q_learning_agent._padded(), 256, 2, seed=SELECTION_SEED, device=0), max_attempts=3, accept_touchdown=accept)
+
+    strip = lambda hist: [{k: v for k, v in h.items() if not k.startswith("wall")} for h in hist]
+    # nothing acceptable: all three attempts are trained, the best one is kept
+    out, one = two_ranks("two", 2.0), one_process("one", 2.0)
+    assert out["world"] == 2 and len(out["attempts"]) == 3 and not out["accepted"] and out["chosen_attempt"] == one["chosen"]
+    assert [x["selection"] for x in out["attempts"]] == [x["selection"] for x in one["attempts"]]
+    assert len({x["selection"]["touchdown_rate"] for x in out["attempts"]} | {x["selection"]["goal_hold_rate"] for x in out["attempts"]}) > 2  # (the attempts differ)
+    assert strip(out["history"]) == json.loads(json.dumps(strip(one["history"])))
+    for j in range(3):
+        for f in ("Q_table_a.npy", "Q_table_b.npy", "state_action_count.npy"):
+            assert np.array_equal(np.load(tmp_path / "two" / f"attempt{j}" / f), np.load(tmp_path / "one" / f"attempt{j}" / f))
+    # anything acceptable: the first attempt is taken and the others are never trained
+    out0 = two_ranks("two0", 0.0)
+    assert out0["accepted"] and out0["chosen_attempt"] == 0 and len(out0["attempts"]) == 1 and not (tmp_path / "two0" / "attempt1").exists()
+
+
 def test_g13_reference_env_outputs_through_the_hip_engine(golden_dir):
     """a17-a19 on the GPU: the fixture's fake Gazebo played back a flight of this simulator to the REFERENCE's TrainingLandingEnv /
     SimulationLandingEnv; here the HIP engine (one env, float64, same seed and actions) flies it again: identical signals, and per
