@@ -65,19 +65,24 @@ DQL_DEV float sqrt_(float x) {
   return y;
 }
 DQL_DEV double sqrt_(double a) { return __builtin_sqrt(a); }
-// Correctly rounded sqrt for x >= 2^-102 in 1 transcendental + 7 full-rate instructions (v_rsq_f32, one Goldschmidt step on (x y, y / 2), one
-// residual correction — the sequence LLVM lowers an IEEE sqrt to when denormals are flushed) instead of sqrt_'s v_sqrt_f32 + 8 mostly four-cycle
-// ones.  EXHAUSTIVELY verified on gfx950: every one of the 2.13e9 positive normal float32 inputs against (float)sqrt((double)x) — the only
-// 1.8 M misroundings all lie below 2^-103, where the residual goes subnormal (tools/micro/sqrt_exhaustive.hip,
-// profiles/r3_sqrt_rsq_goldschmidt_exhaustive.jsonl; dql_selftest_sqrt re-runs the check inside this library).  The tick's four rotor
-// commands per physics tick use it on max(w^2, 1e-30).
+// Correctly rounded sqrt for x >= 2^-102 in 1 transcendental + 4 full-rate instructions: v_rsq_f32 (1 ulp), g = x y, and ONE residual correction
+// g + (x - g^2) (y / 2) with the residual exact in the fma.  Rounds 3 - 5 (until their last hours) ran the sequence LLVM lowers an IEEE sqrt to when denormals
+// are flushed — a Goldschmidt step on (g, y / 2) before the correction, 1 + 7 instructions; the step is not needed on this hardware: EXHAUSTIVELY verified on
+// gfx950, every one of the 2.13e9 positive normal float32 inputs against (float)sqrt((double)x), both sequences misround only below 2^-102 (1.80 M and 1.84 M
+// inputs, largest 0x0c7fffff), where the residual goes subnormal (tools/micro/sqrt_variants.hip, profiles/r5_sqrt_variants_exhaustive.jsonl; round 3:
+// tools/micro/sqrt_exhaustive.hip; dql_diag_selftest_sqrt re-runs the check on THIS function inside the library).  v_sqrt_f32 alone misrounds 15 % of all inputs.
+// The tick's four rotor commands per physics tick use it on med3(w^2, 1e-30, omax^2); instead of sqrt_'s v_sqrt_f32 + 8 mostly four-cycle ones.
 constexpr float SQRT_POS_MIN = 1e-30f;  // > 2^-102 = 1.97e-31
 DQL_DEV float sqrt_pos(float x) {
   const float y = __builtin_amdgcn_rsqf(x);
+#ifdef DQL_AB_SQRT_GOLDSCHMIDT  // A/B builds (tools/ab_build.sh): the 1 + 7 sequence
   float g = x * y, h = 0.5f * y;
   const float r = __builtin_fmaf(-h, g, 0.5f);
   g = __builtin_fmaf(g, r, g);
   h = __builtin_fmaf(h, r, h);
+#else
+  const float g = x * y, h = 0.5f * y;
+#endif
   const float d = __builtin_fmaf(-g, g, x);
   return __builtin_fmaf(d, h, g);
 }
@@ -1005,18 +1010,19 @@ DQL_DEV void manager_obs(const SimK<T>& s, Env<T>& e, T cy, T sy, long long mgr_
   platform_update(s, e, rec, mgr_in_step == 0);
 }
 // platform extrapolation between manager ticks + bumper contact test
-template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e) {
+template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e, T low_z) {
   e.mp_x = fma_(e.mp_u, s.dt, e.mp_x); e.mp_y = fma_(e.mp_v, s.dt, e.mp_y);
   // the footprint test only where some lane of the wave is low enough to touch (a real branch: a training flight descends at 0.1 m/s from
   // 4 m and ends after 20 s at the latest — it never gets there, and the tick pays two instructions instead of eight)
   bool low;
-  if constexpr (Fast32<T>::on) low = e.p[2] <= T(s.low_z);  // round 4b: against the host's mp_top + bottom
+  if constexpr (Fast32<T>::on) low = e.p[2] <= low_z;  // round 4b: against the host's mp_top + bottom (low_z: s.low_z, from a register of the caller's choosing)
   else low = e.p[2] - s.bottom <= s.mp_top;
   if (__ballot(low) != 0ull) {
     asm volatile("; footprint test" ::: "memory");  // keeps the block a block: the compiler otherwise flattens it into selects again
     if (low && abs_(e.p[0] - e.mp_x) <= s.mp_hx && abs_(e.p[1] - e.mp_y) <= s.mp_hy) e.flags |= FL_CONTACT;
   }
 }
+template <typename T, typename K> DQL_DEV void platform_contact(const K& s, Env<T>& e) { platform_contact(s, e, T(s.low_z)); }
 // B = Rx(roll_sp) Ry(pitch_sp) (attitude_controller.py:138-140), constant over one agent period
 template <typename T> DQL_DEV void make_B(T pitch_sp, T roll_sp, T (&B)[9]) {
   T sp_, cp_, sr_, cr_;
@@ -1504,10 +1510,13 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
   // The literal layout's constants are instruction literals — which gfx9's three-operand encodings (v_med3, v_fma with an inline constant) cannot carry: for the yaw
   // PID's clamp bounds and the yaw frame's 0.375 the compiler emitted an s_mov of the literal in front of EVERY use, three scalar instructions per physics tick.
   // Pinned to SGPRs here (opaque: nothing to rematerialise) they stay scalar operands — in VGPRs they cost more than the s_movs (three VGPR sources per v_med3).
-  T yw_lo = T(h.yw_lo), yw_hi = T(h.yw_hi), yw_wind = T(h.yw_wind), c375 = T(0.375);
+  T yw_lo = T(h.yw_lo), yw_hi = T(h.yw_hi), yw_wind = T(h.yw_wind), c375 = T(0.375), low_z = T(h.low_z);
 #ifndef DQL_AB_NO_TICK_SREGS  // A/B builds (tools/ab_build.sh)
   if constexpr (sizeof(T) == 4 && TICK == TICK_LIT) {
     asm volatile("" : "+s"(yw_wind), "+s"(yw_hi), "+s"(c375));
+#ifndef DQL_AB_NO_LOWZ_SREG
+    asm volatile("" : "+s"(low_z));  // (the contact test's height: the literal was moved into a scalar register in front of the compare at every tick)
+#endif
     if (T(h.yw_lo) == -T(h.yw_hi)) yw_lo = -yw_hi;
   }
 #endif
@@ -1550,7 +1559,7 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
     plant_step(h, e, R);
     rotor_filter<true>(h, e, cmd);
     DQL_SECTION("platform_contact");
-    platform_contact(h, e);
+    platform_contact(h, e, low_z);
   };
   if constexpr (sizeof(T) == 4 && tick_is_packed(TICK)) {
     // float32: the packed tick (physics_tick_pk): the state the 500 Hz loop touches lives in register pairs for the whole period
@@ -1613,6 +1622,11 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
     // (physics ticks to go until the next manager tick, counted down: a compare + branch per tick; the phase counted up and wrapped cost an add, a compare,
     //  a select and the compare + branch)
     int togo = phase == 0 ? 0 : s.div - phase;
+    // (the tick loop holds one s_waitcnt vmcnt(0) although it has no memory instruction — a load of the period's beginning is still pending on one path into it.
+    //  Waiting in front of the loop instead removes 22 scalar instructions per period and is 0.3 % SLOWER, 17.19 against 17.14 us: the first tick hides that
+    //  load's latency; profiles/r5_ab_tick_loop.txt)
+    // (round 5 tried the runs of plain ticks between two manager ticks as an inner loop of their own — one counter, one compare + branch per tick, the tick's body
+    //  twice in the code: 17.47 against 17.18 us per period, profiles/r5_ab_tick_loop.txt)
 #pragma unroll TickUnroll<T>::n
     for (int i = 0; i < n_ticks; ++i) {
       DQL_SECTION("rot");

@@ -29,7 +29,7 @@ int dql_diag_delay(dql_ctx* ctx, double microseconds);
 int dql_diag_accum_dev_ptr(dql_ctx* ctx, void** dev_ptr, int64_t* n_int64);
 
 /* ---- self-test ---- */
-/* The float32 tick's square root (csrc/dql_device.hpp sqrt_pos: v_rsq_f32 + Goldschmidt step + residual correction): counts the inputs with bit
+/* The float32 tick's square root (csrc/dql_device.hpp sqrt_pos: v_rsq_f32 + one residual correction; until the end of round 5 with a Goldschmidt step in between): counts the inputs with bit
  * patterns lo_bits .. hi_bits whose result is NOT the correctly rounded sqrt.  The CPU oracle computes sqrtf(); parity is bit for bit only while
  * this count is 0 on the tick's domain [1e-30, FLT_MAX] — all 2.1e9 inputs take under a second. */
 int dql_diag_selftest_sqrt(int device, uint32_t lo_bits, uint32_t hi_bits, int64_t* not_correctly_rounded);

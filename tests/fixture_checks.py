@@ -4,7 +4,7 @@ tests/test_f32_fixtures.py) and the HIP library through its C ABI (tests/test_gp
 
 * float64 spells the reference's expressions out operation by operation: bit-exact (or the fixture's own stand-in tolerance).
 * float32 — the arithmetic every throughput figure runs on — takes the same formulas in shorter forms (transposed Butterworth, fused
-  multiply-adds, x-axis attitude closed form, v_rsq + Goldschmidt root behind one med3 clamp, platform sine / cosine carried by rotation,
+  multiply-adds, x-axis attitude closed form, v_rsq + residual-correction root behind one med3 clamp, platform sine / cosine carried by rotation,
   Kalman fixed-point shortcut, lazy noise).  Each check below states the bound it asserts and where the bound comes from; eps = 2^-24
   (float32 half ulp relative).  The bounds are a priori (rounding analysis), the measured maxima are quoted next to them.
 """
@@ -157,7 +157,7 @@ def _alloc_scale(cfg, thrust, moment):
 def check_g9_rotor_speeds(be, dtype):
     """The reference's rotor speeds sqrt(max(w^2, 0)) for 200 (attitude, body rate, command) samples, incl. the clamp at 0 (112 entries) —
     for float32 through the whole short form: quat_to_R by doubled components, Newton yaw frame, yaw-free attitude error, gains with the
-    halving folded in, fused inverse allocation, med3 clamp, v_rsq + Goldschmidt square root."""
+    halving folded in, fused inverse allocation, med3 clamp, v_rsq + residual-correction square root."""
     g, tilt = _g9()
     cfg = DqlConfig(dtype=dtype)
     rot = be.attitude_run(cfg, g["quat_xyzw"], g["omega"], g["cmd"])

@@ -226,8 +226,8 @@ def test_step_outputs_and_kernel_side_action_check(n):
 
 
 def test_float32_tick_square_root_is_correctly_rounded_on_its_whole_domain(ops):
-    """The float32 tick takes the rotor commands' square roots as v_rsq_f32 + Goldschmidt step + residual correction (1 transcendental + 7
-    full-rate instructions) and the oracle as sqrtf(): bit-for-bit parity needs the former to be THE correctly rounded root.  Exhaustive:
+    """The float32 tick takes the rotor commands' square roots as v_rsq_f32 + one residual correction (1 transcendental + 4 full-rate instructions; rounds 3 - 5
+    ran a Goldschmidt step in between: 1 + 7, tools/micro/sqrt_variants.hip) and the oracle as sqrtf(): bit-for-bit parity needs the former to be THE correctly rounded root.  Exhaustive:
     every float32 from 1e-30 (the tick clamps there) to FLT_MAX — 2.1e9 inputs; and the reason for the clamp: below 2^-103 it is not."""
     assert ops.selftest_sqrt(1e-30, 3.4028234663852886e38) == 0
     assert ops.selftest_sqrt(2.0 ** -102, 1e-30) == 0
@@ -280,7 +280,7 @@ def test_g8_filters_and_pid_on_hip(hip_be, dtype):
 
 @pytest.mark.parametrize("dtype", [F64, 0])
 def test_g9_rotor_speeds_on_hip(hip_be, dtype):
-    """pkg/attitude_controller.py:107-156 (G9) down to the rotor command, v_rsq + Goldschmidt root and med3 clamp included: dql_attitude_run"""
+    """pkg/attitude_controller.py:107-156 (G9) down to the rotor command, v_rsq + residual-correction root and med3 clamp included: dql_attitude_run"""
     fc, hip, _ = hip_be
     fc.check_g9_rotor_speeds(hip, dtype)
     if dtype == 0:
