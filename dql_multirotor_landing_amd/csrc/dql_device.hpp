@@ -1629,6 +1629,9 @@ DQL_DEV StepOut agent_period(const SimK<T>& s_in, const TickConsts<TICK, T>& tc,
     //  twice in the code: 17.47 against 17.18 us per period, profiles/r5_ab_tick_loop.txt)
 #pragma unroll TickUnroll<T>::n
     for (int i = 0; i < n_ticks; ++i) {
+#ifndef DQL_AB_NO_F64_LDS_CONSTS
+      if constexpr (sizeof(T) == 8) asm volatile("" ::: "memory");  // float64: the tick's constants live in LDS (k_step) and are read again in every tick, not held in registers
+#endif
       DQL_SECTION("rot");
       quat_to_R(e.q, R); yaw_cs(R, cy, sy, ct, rn, c375);
       if (togo == 0) { manager_tick(); togo = s.div; }

@@ -311,6 +311,8 @@ constexpr int step_waves_per_simd(int block) { return block == 512 ? 4 : 2; }
 // profiles/r5_f64_two_waves.jsonl; batches of one wave per SIMD pay 1 % for the spills).  Everything else may take up to 512 registers when it runs alone.
 constexpr int step_min_waves_per_simd(int block, int real_size) { return block >= 512 ? step_waves_per_simd(block) : (real_size == 8 && block == 256 ? 2 : 1); }
 template <typename T> DQL_DEV SimK<T> x_only(SimK<T> c) { c.two_axis = 0; return c; }
+template <typename T> struct TickLds { char unused; };
+template <> struct TickLds<double> { SimK<double> k; };
 template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(step_min_waves_per_simd(BLOCK, (int)sizeof(T)), step_waves_per_simd(BLOCK)))) void k_step(StepArgs<T> a) {
   // several waves per workgroup: TD targets meet in LDS first (4x fewer global atomics on the hot cells of a big batch);
   // one wave per workgroup (small batches, latency-bound): 64 envs rarely share a cell, so each lane adds straight into the
@@ -386,7 +388,19 @@ template <typename T, int BLOCK, int TICK, int XMODE> __global__ __launch_bounds
 #ifndef DQL_AB_NO_VGPR_CONSTS  // A/B builds (tools/ab_build.sh)
   if constexpr (sizeof(T) == 4 && BLOCK < 512) cfgk = period_consts_in_vgprs(cfgk);
 #endif
+#ifndef DQL_AB_NO_F64_LDS_CONSTS  // A/B builds (tools/ab_build.sh)
+  // float64: the tick's constants are read from LDS.  As kernel arguments they are SGPR PAIRS — some 150 of them against 100 scalar registers — and the
+  // compiler parked the overflow in VGPR lanes: ~850 v_readlane_b32 per physics tick, three quarters of the tick's instructions, around 264 float64 operations.
+  // One copy per workgroup, read back where used (agent_period's plain loop keeps the compiler from hoisting the reads out of the tick loop again).
+  __shared__ TickLds<T> sTickK;  // (float32: an unused byte)
+  if constexpr (sizeof(T) == 8) {
+    if (tid == 0) sTickK.k = cfgk;
+    __syncthreads();
+  }
+  const TickConsts<TICK, T> tc([&]() -> const SimK<T>& { if constexpr (sizeof(T) == 8) return sTickK.k; else return cfgk; }());
+#else
   const TickConsts<TICK, T> tc(cfgk);
+#endif
   // the Philox round keys (a launch constant) in VGPRs, where there are registers to spare (philox4x32)
   uint32_t kv_[20];
   const uint32_t* kv = nullptr;
