@@ -454,3 +454,61 @@ def test_step_back_falls_back_to_the_promoted_tables_when_the_relearning_fails(t
     assert h[0]["promoted"] and h[1]["promoted"] and not h[2]["promoted"] and h[2]["exhausted"]
     assert h[2]["step_backs"] == 2 and h[1]["step_backs"] >= 1          # level 1 was learnt again (twice) and fell back to its promoted entry each time
     assert h[1]["restarts"] == 0 and h[1]["wall_first_promoted_s"] is not None
+
+
+def _table_score(tr):
+    """a landing score the CPU can compute (the real one flies the HIP engine): a deterministic function of the final tables, different per attempt"""
+    a = tr._double_q_learning_agent
+    v = float(np.abs(a.Q_table_a).sum() + 3.0 * np.abs(a.Q_table_b).sum())
+    return {"touchdown_rate": (v % 1000.0) / 1000.0, "goal_hold_rate": 0.5}
+
+
+def _attempts_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import json
+    import torch.distributed as dist
+    from _torch_comm import TorchComm
+    import dql_multirotor_landing_amd.trainer as T
+    from dql_multirotor_landing_amd.attempts import attempt_seed, curriculum_attempts
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    T.Engine = _oracle_engine_class()
+    comm = TorchComm()
+    scored = []
+
+    def score(tr):
+        scored.append(rank)
+        return _table_score(tr)
+    res = curriculum_attempts(lambda j: T.Trainer(save_path=Path(out_dir) / f"run{j}", comm=comm, **{**TR_KW, "seed": attempt_seed(TR_KW.get("seed", 42), j)}), score,
+                              max_attempts=3, accept_touchdown=2.0, comm=comm, rank=rank, close=lambda tr: None)
+    assert scored == ([0, 0, 0] if rank == 0 else [])   # rank 0 alone scores; the other rank gets the figures through the all-reduce
+    qa, qb, cnt = res["trainer"]._engine.get_tables()
+    np.savez(Path(out_dir) / f"attempts_rank{rank}.npz", qa=qa, count=cnt)
+    (Path(out_dir) / f"attempts{rank}.json").write_text(json.dumps({"chosen": res["chosen"], "accepted": res["accepted"], "selection": [a["selection"] for a in res["attempts"]],
+                                                                      "promoted": [a["promoted_levels"] for a in res["attempts"]], "history": _strip(res["history"])}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_curriculum_attempts_two_ranks_equal_single_process(tmp_path, monkeypatch):
+    """Several whole curricula (attempts.py) with the real Trainer sharded over two ranks (gloo, oracle engine): both ranks choose the same attempt on rank 0's
+    scores, and attempts, scores, choice and chosen tables are those of one process."""
+    import json
+    import torch.multiprocessing as mp
+    import dql_multirotor_landing_amd.trainer as T
+    from dql_multirotor_landing_amd.attempts import attempt_seed, curriculum_attempts
+    mp.spawn(_attempts_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.loads((tmp_path / f"attempts{r}.json").read_text()) for r in range(2))
+    assert r0 == r1 and len(r0["selection"]) == 3 and not r0["accepted"]
+    assert len({s["touchdown_rate"] for s in r0["selection"]}) == 3   # three different runs
+    best = max(range(3), key=lambda k: (r0["promoted"][k], r0["selection"][k]["touchdown_rate"], -k))
+    assert r0["chosen"] == best
+    monkeypatch.setattr(T, "Engine", _oracle_engine_class())
+    one = curriculum_attempts(lambda j: T.Trainer(save_path=tmp_path / f"single{j}", **{**TR_KW, "seed": attempt_seed(TR_KW.get("seed", 42), j)}), _table_score,
+                              max_attempts=3, accept_touchdown=2.0, close=lambda tr: None)
+    assert one["chosen"] == r0["chosen"] and [a["selection"] for a in one["attempts"]] == r0["selection"]
+    assert json.loads(json.dumps(_strip(one["history"]))) == r0["history"]
+    qa, _, cnt = one["trainer"]._engine.get_tables()
+    for r in range(2):
+        z = np.load(tmp_path / f"attempts_rank{r}.npz")
+        np.testing.assert_array_equal(z["qa"], qa)
+        np.testing.assert_array_equal(z["count"], cnt)
